@@ -1,0 +1,150 @@
+/*
+ * parrm_hip.h -- C ABI of the MI355X (gfx950) PARRM hot path.
+ *
+ * Drop-in boundary for neuromodulation/PyPARRM v1.2.0dev (pure Python; there is no FFI in
+ * the reference, so each entry point below names the reference expression it replaces,
+ * file:line relative to /root/reference, `parrm.py` = src/pyparrm/parrm.py).
+ *
+ * Conventions
+ *   - every `d_*` pointer is a DEVICE pointer valid on the current HIP device; `h_*` is host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Nothing here
+ *     synchronises the stream unless its comment says so.
+ *   - recordings are row-major [n_chans][n_samples] with a row stride `ld` in ELEMENTS
+ *     (the reference's C-order ndarray, parrm.py:102-110).
+ *   - every function returns PARRM_OK (0) or a PARRM_ERR_* code; the message of the last
+ *     failure on the calling thread is available from parrm_hip_last_error().  No
+ *     exceptions cross this boundary; the Python facade turns codes into exceptions.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *     fails with PARRM_ERR_NO_DEVICE / PARRM_ERR_HIP.
+ */
+#ifndef PARRM_HIP_H
+#define PARRM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARRM_HIP_ABI_VERSION 1
+
+#define PARRM_OK 0
+#define PARRM_ERR_INVALID 1   /* bad argument (NULL, negative size, unsupported dtype...) */
+#define PARRM_ERR_HIP 2       /* a HIP runtime call failed                                */
+#define PARRM_ERR_NO_DEVICE 3 /* no HIP device visible                                    */
+#define PARRM_ERR_WORKSPACE 4 /* caller-provided workspace too small                      */
+#define PARRM_ERR_EMPTY_FILTER 5 /* filter has no taps (parrm.py:822-827 raises before this) */
+
+/* element types of a recording */
+#define PARRM_F32 0
+#define PARRM_F64 1
+
+/* filter kernel variants (parrm_filter_plan_set_kernel) */
+#define PARRM_KERNEL_AUTO 0
+#define PARRM_KERNEL_GATHER 1 /* one thread per output, taps gathered from global/L2        */
+#define PARRM_KERNEL_STRIDE 2 /* LDS ring + stride-q running-sum recurrence (the fast path)  */
+
+int parrm_hip_abi_version(void);
+const char *parrm_hip_last_error(void);
+/* number of visible HIP devices (0 and PARRM_OK when there is none) */
+int parrm_hip_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------
+ * filter_data  (parrm.py:835-875; arithmetic at :861-869)
+ *
+ *   y[c,n] = x[c,n] - mean{ x[c,n-w] : w in taps, 0 <= n-w < n_total }, 0 where no tap is
+ *   in range, 0 where the result is not finite (:869).
+ *
+ * A plan is built from the reference's dense filter array `PARRM._filter`
+ * (parrm.py:803-833: 1 at the centre, -1/S on taps, 0 elsewhere; length 2*hw+1).  Building
+ * the plan derives the tap runs, picks the recurrence stride q and uploads the tables to
+ * the current device (synchronous).  A plan is bound to the device it was created on.
+ * ------------------------------------------------------------------------------------ */
+typedef struct parrm_filter_plan parrm_filter_plan;
+
+typedef struct parrm_filter_plan_info {
+    int64_t half_width;  /* hw                                                         */
+    int64_t n_taps;      /* S                                                          */
+    int64_t n_runs;      /* maximal runs of consecutive taps                           */
+    int64_t stride;      /* q of the stride recurrence (0 when the variant is unusable)*/
+    int64_t n_delta;     /* signed taps of d_q = tap(.+q) - tap(.)                     */
+    int64_t ring_len;    /* LDS ring length in samples                                 */
+    int64_t rows_per_fill; /* rows of q samples loaded per fill                        */
+    int32_t block_threads;
+    int32_t kernel;      /* variant AUTO resolves to                                   */
+} parrm_filter_plan_info;
+
+int parrm_filter_plan_create(const double *h_filter, int64_t filter_len,
+                             parrm_filter_plan **plan);
+int parrm_filter_plan_destroy(parrm_filter_plan *plan);
+int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_info *info);
+int parrm_filter_plan_set_kernel(parrm_filter_plan *plan, int kernel);
+
+/* Whole recording resident on the device: x[n_chans][n_samples] -> y[n_chans][n_samples].
+ * x_dtype in {PARRM_F32, PARRM_F64}; y_dtype PARRM_F64 (the reference's dtype rule: float32
+ * in -> float64 out) or PARRM_F32 (build option, only with x_dtype PARRM_F32).  x and y
+ * must not overlap. */
+int parrm_filter_apply(const parrm_filter_plan *plan, const void *d_x, int x_dtype, void *d_y,
+                       int y_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
+                       int64_t ldy, void *stream);
+
+/* Time-window form for chunk streaming: d_x holds samples [buf_first, buf_first+buf_len) of
+ * a recording of n_total samples (row stride ldx); outputs [out_first, out_first+out_len)
+ * are written to d_y[c*ldy + (n - out_first)].  The window must contain
+ * [max(out_first-hw,0), min(out_first+out_len+hw, n_total)). */
+int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, int x_dtype,
+                              void *d_y, int y_dtype, int64_t n_chans, int64_t buf_first,
+                              int64_t buf_len, int64_t out_first, int64_t out_len,
+                              int64_t n_total, int64_t ldx, int64_t ldy, void *stream);
+
+/* Host-resident recording, streamed through the device in time chunks of `chunk_samples`
+ * (0 = pick) with pinned double buffers and two streams; synchronous. */
+int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtype, void *h_y,
+                      int y_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
+                      int64_t ldy, int64_t chunk_samples);
+
+/* ------------------------------------------------------------------------------------
+ * find_period, statistics pass  (parrm.py:272-280, `_standardise_data`)
+ *
+ *   d_scale[c] = mean_i |x[c,i+1] - x[c,i]|            (:274-275)
+ * One streaming read of the recording; deterministic two-level reduction.
+ * ------------------------------------------------------------------------------------ */
+size_t parrm_absdiff_workspace_bytes(int64_t n_chans, int64_t n_samples);
+int parrm_absdiff_mean(const void *d_x, int x_dtype, int64_t n_chans, int64_t n_samples,
+                       int64_t ldx, double *d_scale, void *d_workspace, size_t workspace_bytes,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * find_period, gather of the standardised columns one stage consumes
+ * (parrm.py:274-278 composed with `data_chan[indices]`, :590)
+ *
+ *   d_y[j*ldy + c] = clip((x[c,idx[j]+1] - x[c,idx[j]]) / d_scale[c], +-outlier_boundary)
+ * Sample-major [n_idx][ldy] layout, ldy >= n_chans.  Requires 0 <= idx[j] < n_samples-1.
+ * ------------------------------------------------------------------------------------ */
+int parrm_gather_standardise(const void *d_x, int x_dtype, int64_t n_chans, int64_t n_samples,
+                             int64_t ldx, const int64_t *d_idx, int64_t n_idx,
+                             const double *d_scale, double outlier_boundary, double *d_y,
+                             int64_t ldy, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * find_period, batched harmonic-regression objective
+ * (`_optimise_local` parrm.py:552-597 over `_fit_waves_to_data` :599-632)
+ *
+ *   for each period T_p:  angles = (idx+1) * (2*pi/T_p)                          (:619)
+ *     W = [1, sin(k*angles), cos(k*angles)]_{k=1..bw}                            (:620-623)
+ *     beta_c = solve(W'W, W'y_c)   (LU, partial pivoting; exact zero pivot -> +inf) (:626-628)
+ *     err_p = mean_c [ mean_j (y_cj - W_j beta_c)^2 + sum_k regu_k beta_ck^2 ]    (:595-597)
+ *   regu_k = lambda * k / sum(1..K), K = 2*bw+1                                   (:585-586)
+ * d_y is the [n_idx][ldy] matrix written by parrm_gather_standardise.  bw <= 23.
+ * ------------------------------------------------------------------------------------ */
+size_t parrm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw);
+int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
+                     int64_t n_chans, const double *d_periods, int64_t n_periods, int bw,
+                     double lambda, double *d_err, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARRM_HIP_H */

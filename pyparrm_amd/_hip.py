@@ -1,0 +1,349 @@
+"""ctypes binding of the gfx950 C-ABI library (``include/parrm_hip.h``) plus the torch plumbing
+(device buffers, current stream) the façade needs.
+
+There is deliberately no CPU fallback here: if the library is missing or no GPU is visible,
+every compute entry point raises.  PyTorch is used only to own device memory and streams.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libparrm_hip.so")
+
+F32, F64 = 0, 1
+KERNEL_AUTO, KERNEL_GATHER, KERNEL_STRIDE = 0, 1, 2
+
+# every symbol include/parrm_hip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "parrm_hip_abi_version",
+    "parrm_hip_last_error",
+    "parrm_hip_device_count",
+    "parrm_filter_plan_create",
+    "parrm_filter_plan_destroy",
+    "parrm_filter_plan_query",
+    "parrm_filter_plan_set_kernel",
+    "parrm_filter_apply",
+    "parrm_filter_apply_window",
+    "parrm_filter_host",
+    "parrm_absdiff_workspace_bytes",
+    "parrm_absdiff_mean",
+    "parrm_gather_standardise",
+    "parrm_fit_workspace_bytes",
+    "parrm_fit_errors",
+)
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [
+        ("half_width", C.c_int64),
+        ("n_taps", C.c_int64),
+        ("n_runs", C.c_int64),
+        ("stride", C.c_int64),
+        ("n_delta", C.c_int64),
+        ("ring_len", C.c_int64),
+        ("rows_per_fill", C.c_int64),
+        ("block_threads", C.c_int32),
+        ("kernel", C.c_int32),
+    ]
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP extension is missing, unloadable, or a call into it failed."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load ``libparrm_hip.so`` (once) and declare its signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise HipLibraryError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C pyparrm_amd/csrc`. pyparrm_amd has no CPU fallback."
+            )
+        # torch bundles its own HIP runtime (soname libamdhip64.so.7, the one this library
+        # links against): import it first so both share ONE runtime; loading ours first would
+        # pull in /opt/rocm's copy and leave the process with two.
+        import torch  # noqa: F401
+
+        try:
+            L = C.CDLL(_LIB_PATH)
+        except OSError as exc:  # e.g. libamdhip64 not found
+            raise HipLibraryError(f"cannot load {_LIB_PATH}: {exc}") from exc
+        i64, vp, dbl, i32 = C.c_int64, C.c_void_p, C.c_double, C.c_int
+        L.parrm_hip_abi_version.restype = i32
+        L.parrm_hip_abi_version.argtypes = []
+        L.parrm_hip_last_error.restype = C.c_char_p
+        L.parrm_hip_last_error.argtypes = []
+        L.parrm_hip_device_count.restype = i32
+        L.parrm_hip_device_count.argtypes = [C.POINTER(i32)]
+        L.parrm_filter_plan_create.restype = i32
+        L.parrm_filter_plan_create.argtypes = [vp, i64, C.POINTER(vp)]
+        L.parrm_filter_plan_destroy.restype = i32
+        L.parrm_filter_plan_destroy.argtypes = [vp]
+        L.parrm_filter_plan_query.restype = i32
+        L.parrm_filter_plan_query.argtypes = [vp, C.POINTER(PlanInfo)]
+        L.parrm_filter_plan_set_kernel.restype = i32
+        L.parrm_filter_plan_set_kernel.argtypes = [vp, i32]
+        L.parrm_filter_apply.restype = i32
+        L.parrm_filter_apply.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
+        L.parrm_filter_apply_window.restype = i32
+        L.parrm_filter_apply_window.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, vp]
+        L.parrm_filter_host.restype = i32
+        L.parrm_filter_host.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64]
+        L.parrm_absdiff_workspace_bytes.restype = C.c_size_t
+        L.parrm_absdiff_workspace_bytes.argtypes = [i64, i64]
+        L.parrm_absdiff_mean.restype = i32
+        L.parrm_absdiff_mean.argtypes = [vp, i32, i64, i64, i64, vp, vp, C.c_size_t, vp]
+        L.parrm_gather_standardise.restype = i32
+        L.parrm_gather_standardise.argtypes = [vp, i32, i64, i64, i64, vp, i64, vp, dbl, vp, i64, vp]
+        L.parrm_fit_workspace_bytes.restype = C.c_size_t
+        L.parrm_fit_workspace_bytes.argtypes = [i64, i64, i64, i32]
+        L.parrm_fit_errors.restype = i32
+        L.parrm_fit_errors.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
+        if L.parrm_hip_abi_version() != 1:
+            raise HipLibraryError("libparrm_hip.so has an unexpected ABI version")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().parrm_hip_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what or 'parrm_hip'} failed (code {rc}): {msg}")
+
+
+def require_gpu():
+    """Return the torch module after making sure a HIP device is usable; raise loudly otherwise."""
+    L = lib()
+    import torch
+
+    n = C.c_int(0)
+    check(L.parrm_hip_device_count(C.byref(n)), "parrm_hip_device_count")
+    if n.value == 0 or not torch.cuda.is_available():
+        raise HipLibraryError(
+            "no MI355X/HIP device is visible: pyparrm_amd runs find_period/filter_data on the GPU "
+            "only (there is no CPU fallback)."
+        )
+    return torch
+
+
+def _stream_ptr(torch) -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _dtype_code(t) -> int:
+    import torch
+
+    if t.dtype == torch.float64:
+        return F64
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported device dtype {t.dtype}; use float32 or float64")
+
+
+def _check_rows(t, name: str) -> None:
+    if t.dim() != 2 or not t.is_cuda:
+        raise ValueError(f"`{name}` must be a 2-D CUDA tensor")
+    if t.shape[1] > 0 and t.stride(1) != 1:
+        raise ValueError(f"`{name}` must be contiguous along time")
+
+
+class FilterPlan:
+    """Device-side plan for one PARRM filter (``parrm_filter_plan_*``)."""
+
+    def __init__(self, filt: np.ndarray):
+        self._h = C.c_void_p(None)
+        require_gpu()
+        f = np.ascontiguousarray(filt, dtype=np.float64)
+        if f.ndim != 1:
+            raise ValueError("filter must be 1-D")
+        check(
+            lib().parrm_filter_plan_create(f.ctypes.data_as(C.c_void_p), f.shape[0], C.byref(self._h)),
+            "parrm_filter_plan_create",
+        )
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value and _lib is not None:
+            _lib.parrm_filter_plan_destroy(h)
+
+    @property
+    def info(self) -> PlanInfo:
+        out = PlanInfo()
+        check(lib().parrm_filter_plan_query(self._h, C.byref(out)), "parrm_filter_plan_query")
+        return out
+
+    def set_kernel(self, kernel: int) -> None:
+        check(lib().parrm_filter_plan_set_kernel(self._h, kernel), "parrm_filter_plan_set_kernel")
+
+    def apply(self, x, out=None, out_dtype=None):
+        """y = filter(x) for a device-resident recording ``x[C, N]`` (f32/f64)."""
+        torch = require_gpu()
+        _check_rows(x, "x")
+        if out is None:
+            out = torch.empty(x.shape, dtype=out_dtype or torch.float64, device=x.device)
+        _check_rows(out, "out")
+        if out.shape != x.shape:
+            raise ValueError("`out` must have the shape of `x`")
+        n_chans, n_samples = x.shape
+        if n_chans == 0 or n_samples == 0:
+            return out
+        ldx = x.stride(0) if n_chans > 1 else max(x.stride(0), n_samples)
+        ldy = out.stride(0) if n_chans > 1 else max(out.stride(0), n_samples)
+        with torch.cuda.device(x.device):
+            check(
+                lib().parrm_filter_apply(
+                    self._h, x.data_ptr(), _dtype_code(x), out.data_ptr(), _dtype_code(out),
+                    n_chans, n_samples, ldx, ldy, _stream_ptr(torch),
+                ),
+                "parrm_filter_apply",
+            )
+        return out
+
+    def apply_window(self, x, buf_first: int, out_first: int, out_len: int, n_total: int, out=None):
+        """Outputs [out_first, out_first+out_len) of a recording of ``n_total`` samples, of which
+        ``x[C, buf_len]`` holds samples [buf_first, buf_first+buf_len)."""
+        torch = require_gpu()
+        _check_rows(x, "x")
+        if out is None:
+            out = torch.empty((x.shape[0], out_len), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            check(
+                lib().parrm_filter_apply_window(
+                    self._h, x.data_ptr(), _dtype_code(x), out.data_ptr(), _dtype_code(out), x.shape[0],
+                    buf_first, x.shape[1], out_first, out_len, n_total,
+                    max(x.stride(0), x.shape[1]), max(out.stride(0), out_len), _stream_ptr(torch),
+                ),
+                "parrm_filter_apply_window",
+            )
+        return out
+
+    def apply_host(self, x: np.ndarray, out_dtype=np.float64, chunk_samples: int = 0) -> np.ndarray:
+        """Stream a host-resident recording through the device in time chunks."""
+        require_gpu()
+        if x.dtype not in (np.float32, np.float64):
+            x = x.astype(np.float64)
+        x = np.ascontiguousarray(x)
+        y = np.empty(x.shape, dtype=out_dtype)
+        code_x = F64 if x.dtype == np.float64 else F32
+        code_y = F64 if y.dtype == np.float64 else F32
+        check(
+            lib().parrm_filter_host(
+                self._h, x.ctypes.data_as(C.c_void_p), code_x, y.ctypes.data_as(C.c_void_p), code_y,
+                x.shape[0], x.shape[1], x.shape[1], x.shape[1], chunk_samples,
+            ),
+            "parrm_filter_host",
+        )
+        return y
+
+
+def absdiff_mean(x):
+    """scale[c] = mean_i |x[c,i+1]-x[c,i]| on the device (parrm.py:274-275)."""
+    torch = require_gpu()
+    _check_rows(x, "x")
+    n_chans, n_samples = x.shape
+    ws_bytes = lib().parrm_absdiff_workspace_bytes(n_chans, n_samples)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x.device)
+    scale = torch.empty(n_chans, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(
+            lib().parrm_absdiff_mean(
+                x.data_ptr(), _dtype_code(x), n_chans, n_samples, max(x.stride(0), n_samples),
+                scale.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(torch),
+            ),
+            "parrm_absdiff_mean",
+        )
+    return scale
+
+
+def gather_standardise(x, idx, scale, outlier_boundary: float):
+    """Y[j, c] = clip((x[c,idx_j+1]-x[c,idx_j])/scale[c], +-ob); returns a [n_idx, C] f64 tensor."""
+    torch = require_gpu()
+    _check_rows(x, "x")
+    n_chans, n_samples = x.shape
+    y = torch.empty((idx.shape[0], n_chans), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(
+            lib().parrm_gather_standardise(
+                x.data_ptr(), _dtype_code(x), n_chans, n_samples, max(x.stride(0), n_samples),
+                idx.data_ptr(), idx.shape[0], scale.data_ptr(), float(outlier_boundary),
+                y.data_ptr(), n_chans, _stream_ptr(torch),
+            ),
+            "parrm_gather_standardise",
+        )
+    return y
+
+
+class FitWorkspace:
+    """Grow-only device scratch for ``parrm_fit_errors`` (one per stage; avoids per-call mallocs)."""
+
+    MAX_BYTES = 4 << 30
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes: int, device):
+        torch = require_gpu()
+        if self._buf is None or self._buf.numel() * 8 < nbytes or self._buf.device != device:
+            self._buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+        return self._buf
+
+
+def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, workspace: FitWorkspace | None = None):
+    """Channel-averaged regularised fit error of every candidate period (parrm.py:552-632).
+
+    ``y`` is the [n_idx, C] matrix from :func:`gather_standardise`, ``idx`` the int64 device vector
+    of sample indices.  Returns a float64 NumPy vector (one blocking read-back per call).
+    """
+    torch = require_gpu()
+    L = lib()
+    periods = np.ascontiguousarray(np.asarray(periods, dtype=np.float64).reshape(-1))
+    n_idx, n_chans = y.shape
+    n_per = periods.shape[0]
+    out = np.empty(n_per, dtype=np.float64)
+    if n_per == 0:
+        return out
+    ws = workspace or FitWorkspace()
+    # batch so that the scratch stays bounded
+    per_one = L.parrm_fit_workspace_bytes(n_idx, n_chans, 1, bandwidth)
+    if per_one == 0:
+        raise HipLibraryError("parrm_fit_workspace_bytes rejected the problem shape")
+    batch = n_per
+    while batch > 1 and L.parrm_fit_workspace_bytes(n_idx, n_chans, batch, bandwidth) > FitWorkspace.MAX_BYTES:
+        batch = (batch + 1) // 2
+    batch = min(batch, 65535)
+    d_per = torch.from_numpy(periods).to(y.device)
+    d_err = torch.empty(n_per, dtype=torch.float64, device=y.device)
+    with torch.cuda.device(y.device):
+        stream = _stream_ptr(torch)
+        for lo in range(0, n_per, batch):
+            cnt = min(batch, n_per - lo)
+            nbytes = L.parrm_fit_workspace_bytes(n_idx, n_chans, cnt, bandwidth)
+            buf = ws.get(nbytes, y.device)
+            check(
+                L.parrm_fit_errors(
+                    y.data_ptr(), y.stride(0), idx.data_ptr(), n_idx, n_chans,
+                    d_per.data_ptr() + 8 * lo, cnt, int(bandwidth), float(lambda_),
+                    d_err.data_ptr() + 8 * lo, buf.data_ptr(), nbytes, stream,
+                ),
+                "parrm_fit_errors",
+            )
+    out[:] = d_err.cpu().numpy()
+    return out

@@ -1,0 +1,144 @@
+// ABI plumbing: error strings, version, device count, and the host-buffer streaming form of
+// filter_data (BASELINE config 5: recordings larger than HBM, or simply host-resident).
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "parrm_common.h"
+
+namespace parrm {
+
+static thread_local char g_last_error[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t err, const char *what) {
+    set_error("%s: %s (%s)", what, hipGetErrorString(err), hipGetErrorName(err));
+    return err == hipErrorNoDevice ? PARRM_ERR_NO_DEVICE : PARRM_ERR_HIP;
+}
+
+}  // namespace parrm
+
+namespace {
+
+struct StreamRes {
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    void *d_in[2] = {nullptr, nullptr};
+    void *d_out[2] = {nullptr, nullptr};
+    ~StreamRes() {
+        for (int i = 0; i < 2; ++i) {
+            if (d_in[i]) (void)hipFree(d_in[i]);
+            if (d_out[i]) (void)hipFree(d_out[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (stream[i]) (void)hipStreamDestroy(stream[i]);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int parrm_hip_abi_version(void) { return PARRM_HIP_ABI_VERSION; }
+
+const char *parrm_hip_last_error(void) { return parrm::g_last_error; }
+
+int parrm_hip_device_count(int *count) {
+    PARRM_REQUIRE(count, "device_count: NULL argument");
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) {
+        *count = 0;
+        return PARRM_OK;
+    }
+    if (e != hipSuccess) {
+        *count = 0;
+        return parrm::hip_fail(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return PARRM_OK;
+}
+
+// Time-chunked streaming: chunk k covers outputs [k*chunk, (k+1)*chunk) and is uploaded with a
+// half-width halo on each side (stencil locality, SURVEY.md 5 "long-context").  Two streams, two
+// device buffer pairs: upload/compute/download of chunk k+1 overlaps chunk k.  The host buffers are
+// page-locked for the duration of the call so the copies are true async DMA.
+int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtype, void *h_y, int y_dtype,
+                      int64_t n_chans, int64_t n_samples, int64_t ldx, int64_t ldy, int64_t chunk_samples) {
+    PARRM_REQUIRE(plan && h_x && h_y, "filter_host: NULL argument");
+    PARRM_REQUIRE(x_dtype == PARRM_F32 || x_dtype == PARRM_F64, "filter_host: bad x_dtype %d", x_dtype);
+    PARRM_REQUIRE(y_dtype == PARRM_F64 || (y_dtype == PARRM_F32 && x_dtype == PARRM_F32),
+                  "filter_host: y_dtype must be f64, or f32 for f32 input");
+    PARRM_REQUIRE(n_chans >= 0 && n_samples >= 0 && ldx >= n_samples && ldy >= n_samples, "filter_host: bad shape");
+    if (n_chans == 0 || n_samples == 0) return PARRM_OK;
+    parrm_filter_plan_info info;
+    int rc = parrm_filter_plan_query(plan, &info);
+    if (rc != PARRM_OK) return rc;
+    const int64_t hw = info.half_width;
+    const size_t xs = x_dtype == PARRM_F64 ? 8 : 4, ys = y_dtype == PARRM_F64 ? 8 : 4;
+    if (chunk_samples <= 0) {
+        // ~1 GiB of input per chunk, but never less than a few half-widths (halo overhead <= ~12%)
+        chunk_samples = std::max<int64_t>((int64_t{1} << 30) / static_cast<int64_t>(xs) / n_chans, 16 * hw + 1024);
+    }
+    chunk_samples = std::min(chunk_samples, n_samples);
+    const int64_t n_chunks = (n_samples + chunk_samples - 1) / chunk_samples;
+    const int64_t buf_cap = chunk_samples + 2 * hw;
+
+    StreamRes r;
+    const int nbuf = n_chunks > 1 ? 2 : 1;
+    for (int i = 0; i < nbuf; ++i) {
+        PARRM_HIP_CHECK(hipStreamCreateWithFlags(&r.stream[i], hipStreamNonBlocking));
+        PARRM_HIP_CHECK(hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
+        PARRM_HIP_CHECK(hipMalloc(&r.d_in[i], static_cast<size_t>(n_chans * buf_cap) * xs));
+        PARRM_HIP_CHECK(hipMalloc(&r.d_out[i], static_cast<size_t>(n_chans * chunk_samples) * ys));
+    }
+    // page-lock the caller's buffers (no staging copy); unlock on every exit path
+    const size_t x_bytes = static_cast<size_t>((n_chans - 1) * ldx + n_samples) * xs;
+    const size_t y_bytes = static_cast<size_t>((n_chans - 1) * ldy + n_samples) * ys;
+    const bool pin_x = hipHostRegister(const_cast<void *>(h_x), x_bytes, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_y = hipHostRegister(h_y, y_bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();  // a refused registration only costs bandwidth
+    auto unpin = [&]() {
+        if (pin_x) (void)hipHostUnregister(const_cast<void *>(h_x));
+        if (pin_y) (void)hipHostUnregister(h_y);
+    };
+
+    hipError_t e = hipSuccess;
+    for (int64_t k = 0; k < n_chunks && e == hipSuccess && rc == PARRM_OK; ++k) {
+        const int b = static_cast<int>(k % nbuf);
+        const int64_t o0 = k * chunk_samples;
+        const int64_t olen = std::min(chunk_samples, n_samples - o0);
+        const int64_t b0 = std::max<int64_t>(o0 - hw, 0);
+        const int64_t b1 = std::min<int64_t>(o0 + olen + hw, n_samples);
+        const int64_t blen = b1 - b0;
+        // stream order on r.stream[b] already serialises reuse of buffer pair b
+        e = hipMemcpy2DAsync(r.d_in[b], static_cast<size_t>(blen) * xs,
+                             static_cast<const char *>(h_x) + static_cast<size_t>(b0) * xs,
+                             static_cast<size_t>(ldx) * xs, static_cast<size_t>(blen) * xs,
+                             static_cast<size_t>(n_chans), hipMemcpyHostToDevice, r.stream[b]);
+        if (e != hipSuccess) break;
+        rc = parrm_filter_apply_window(plan, r.d_in[b], x_dtype, r.d_out[b], y_dtype, n_chans, b0, blen, o0, olen,
+                                       n_samples, blen, olen, r.stream[b]);
+        if (rc != PARRM_OK) break;
+        e = hipMemcpy2DAsync(static_cast<char *>(h_y) + static_cast<size_t>(o0) * ys, static_cast<size_t>(ldy) * ys,
+                             r.d_out[b], static_cast<size_t>(olen) * ys, static_cast<size_t>(olen) * ys,
+                             static_cast<size_t>(n_chans), hipMemcpyDeviceToHost, r.stream[b]);
+    }
+    for (int i = 0; i < nbuf; ++i) {
+        const hipError_t e2 = hipStreamSynchronize(r.stream[i]);
+        if (e == hipSuccess) e = e2;
+    }
+    unpin();
+    if (rc != PARRM_OK) return rc;
+    if (e != hipSuccess) return parrm::hip_fail(e, "filter_host: streaming");
+    return PARRM_OK;
+}
+
+}  // extern "C"

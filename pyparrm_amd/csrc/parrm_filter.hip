@@ -1,0 +1,446 @@
+// filter_data on gfx950: the phase-neighbourhood stencil of parrm.py:861-869 in closed form,
+//
+//   y[c,n] = x[c,n] - (sum_{w in taps, 0<=n-w<N} x[c,n-w]) / #{w in taps : 0<=n-w<N}
+//
+// Two kernels:
+//   * filter_gather_kernel  - one thread per output, taps read from global/L2.  Any half-width,
+//                             any size; used for tiny inputs and as the in-library cross-check.
+//   * filter_stride_kernel  - the fast path.  A workgroup streams one channel-stretch through an
+//                             LDS ring and keeps, per thread, the running tap sum S(n) of one
+//                             residue class mod q:
+//                                 S(n+q) = S(n) + sum_u d_q(u) * xz[n-u],  d_q(u) = tap(u+q) - tap(u)
+//                             d_q is sparse because PARRM taps sit at near-multiples of the artefact
+//                             period: with q ~ a multiple of the period the comb maps onto itself
+//                             except where rounding moves a tooth edge and at the two ends.  That
+//                             turns S=196 LDS reads + adds per output into n_delta (~20-30), which
+//                             is what lets an f64 stencil approach the HBM roofline (SURVEY.md 7,
+//                             hard part 1).  xz is x zero-padded outside [0, N), so the recurrence
+//                             is exact at the recording edges too; only the divisor changes there.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "parrm_common.h"
+
+namespace {
+
+constexpr int kMaxRingLog2F64 = 14;  // 16384 * 8 B = 128 KiB of the 160 KiB LDS
+constexpr int kMaxRowsPerFill = 8;
+constexpr int kMaxBlock = 256;
+
+struct FilterArgs {
+    const void *x;
+    void *y;
+    int64_t n_chans;
+    int64_t buf_first, buf_len;  // samples [buf_first, buf_first+buf_len) are addressable in x
+    int64_t out_first, out_len;  // outputs to produce
+    int64_t n_total;             // length of the whole recording (edge logic)
+    int64_t ldx, ldy;
+    const int32_t *runs;    // [n_runs][2] inclusive tap runs (w_lo, w_hi), ascending
+    const int32_t *tapcum;  // [2*hw+2]: tapcum[j] = #taps with w < j - hw
+    const int32_t *delta;   // [n_plus + n_minus] offsets u of d_q: first the +1 taps, then the -1
+    int32_t n_runs, n_plus, n_minus;
+    int32_t hw, n_taps;
+    int32_t q, ring_mask, rows_per_fill;
+    int64_t stretch_len, n_stretch;
+    double inv_taps;
+};
+
+// number of taps whose source sample n-w lies inside [0, n_total)
+__device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
+    const int64_t hw = a.hw;
+    const int64_t w_hi = n < hw ? n : hw;
+    int64_t w_lo = n - a.n_total + 1;
+    if (w_lo < -hw) w_lo = -hw;
+    if (w_hi < w_lo) return 0;
+    return a.tapcum[w_hi + hw + 1] - a.tapcum[w_lo + hw];
+}
+
+template <typename TO>
+__device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
+    double y;
+    if (n >= a.hw && n + a.hw < a.n_total) {
+        y = xc - s * a.inv_taps;
+    } else {
+        const int v = valid_taps(a, n);
+        y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
+    }
+    if (!isfinite(y)) y = 0.0;  // parrm.py:869
+    static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) filter_gather_kernel(FilterArgs a) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= a.out_len) return;
+    const int64_t n = a.out_first + i;
+    const TI *x = static_cast<const TI *>(a.x);
+    for (int64_t c = blockIdx.y; c < a.n_chans; c += gridDim.y) {
+        const TI *row = x + c * a.ldx - a.buf_first;
+        double s = 0.0;
+        for (int r = 0; r < a.n_runs; ++r) {
+            int64_t lo = n - a.runs[2 * r + 1];
+            int64_t hi = n - a.runs[2 * r];
+            if (lo < 0) lo = 0;
+            if (hi > a.n_total - 1) hi = a.n_total - 1;
+            for (int64_t g = lo; g <= hi; ++g) s += static_cast<double>(row[g]);
+        }
+        emit<TO>(a, c, n, static_cast<double>(row[n]), s);
+    }
+}
+
+template <typename TI>
+__device__ inline TI load_padded(const FilterArgs &a, const TI *row, int64_t g) {
+    // zero outside the recording; the window contract guarantees everything else is addressable
+    const bool ok = g >= 0 && g < a.n_total && g >= a.buf_first && g < a.buf_first + a.buf_len;
+    return ok ? row[g - a.buf_first] : TI(0);
+}
+
+// One workgroup = one (channel, stretch).  Threads r < q own residue r of the stretch; rows of q
+// outputs are produced in lockstep, `rows_per_fill` rows per barrier.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    TI *ring = reinterpret_cast<TI *>(lds_raw);
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int q = a.q;
+    const int mask = a.ring_mask;
+    const int G = a.rows_per_fill;
+    const int hw = a.hw;
+
+    const int64_t blk = blockIdx.x;
+    const int64_t c = blk / a.n_stretch;
+    const int64_t st = blk - c * a.n_stretch;
+    const int64_t s0 = a.out_first + st * a.stretch_len;
+    int64_t s1 = s0 + a.stretch_len;
+    if (s1 > a.out_first + a.out_len) s1 = a.out_first + a.out_len;
+    const int len = static_cast<int>(s1 - s0);
+    const TI *row = static_cast<const TI *>(a.x) + c * a.ldx;
+
+    // prologue: ring <- xz[s0-hw, s0+(G+1)q+hw)
+    int fill = (G + 1) * q + hw;  // exclusive front, relative to s0
+    for (int rel = -hw + tid; rel < fill; rel += nthr) ring[rel & mask] = load_padded(a, row, s0 + rel);
+    __syncthreads();
+
+    const bool active = tid < q;
+    double S = 0.0;
+    if (active) {  // full evaluation once per stretch: S(s0 + tid)
+        double s_a = 0.0, s_b = 0.0;
+        for (int r = 0; r < a.n_runs; ++r) {
+            const int w_lo = a.runs[2 * r], w_hi = a.runs[2 * r + 1];
+            int w = w_lo;
+            for (; w + 1 <= w_hi; w += 2) {
+                s_a += static_cast<double>(ring[(tid - w) & mask]);
+                s_b += static_cast<double>(ring[(tid - w - 1) & mask]);
+            }
+            if (w <= w_hi) s_a += static_cast<double>(ring[(tid - w) & mask]);
+        }
+        S = s_a + s_b;
+    }
+
+    const int n_plus = a.n_plus, n_minus = a.n_minus;
+    const int32_t *dplus = a.delta;
+    const int32_t *dminus = a.delta + n_plus;
+
+    for (int m = 0; m * q < len; m += G) {
+        // 1. issue the next fill's global loads; they land while the rows below are computed
+        const bool more = (m + G) * q < len;  // wave-uniform
+        TI pre[kMaxRowsPerFill];
+        if (more && active) {
+#pragma unroll
+            for (int j = 0; j < kMaxRowsPerFill; ++j)
+                if (j < G) pre[j] = load_padded(a, row, s0 + fill + j * q + tid);
+        }
+        // 2. G rows of outputs
+        if (active) {
+            for (int j = 0; j < G; ++j) {
+                const int rel = (m + j) * q + tid;
+                if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
+                double p0 = 0.0, p1 = 0.0, m0 = 0.0, m1 = 0.0;
+                int i = 0;
+                for (; i + 1 < n_plus; i += 2) {
+                    p0 += static_cast<double>(ring[(rel - dplus[i]) & mask]);
+                    p1 += static_cast<double>(ring[(rel - dplus[i + 1]) & mask]);
+                }
+                if (i < n_plus) p0 += static_cast<double>(ring[(rel - dplus[i]) & mask]);
+                i = 0;
+                for (; i + 1 < n_minus; i += 2) {
+                    m0 += static_cast<double>(ring[(rel - dminus[i]) & mask]);
+                    m1 += static_cast<double>(ring[(rel - dminus[i + 1]) & mask]);
+                }
+                if (i < n_minus) m0 += static_cast<double>(ring[(rel - dminus[i]) & mask]);
+                S += (p0 + p1) - (m0 + m1);
+            }
+        }
+        // 3. publish the prefetched samples (their slots alias data older than row m - see DESIGN.md)
+        if (more) {
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < kMaxRowsPerFill; ++j)
+                    if (j < G) ring[(fill + j * q + tid) & mask] = pre[j];
+            }
+            fill += G * q;
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+struct parrm_filter_plan {
+    int device = 0;
+    int64_t hw = 0, n_taps = 0, n_runs = 0;
+    int64_t q = 0, n_plus = 0, n_minus = 0;
+    int ring_log2_f64 = 0, rows_per_fill = 0, block_threads = 0;
+    int forced_kernel = PARRM_KERNEL_AUTO;
+    int32_t *d_tables = nullptr;  // runs | tapcum | delta, one allocation
+    int64_t off_tapcum = 0, off_delta = 0;
+};
+
+namespace {
+
+int next_pow2_log2(int64_t v) {
+    int l = 0;
+    while ((int64_t{1} << l) < v) ++l;
+    return l;
+}
+
+// Choose the recurrence stride: minimise (LDS reads per output row) / (lane utilisation).
+void choose_stride(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p,
+                   std::vector<int32_t> *delta) {
+    const int64_t L = 2 * hw + 1;
+    double best_cost = 1e300;
+    int64_t best_q = 0;
+    auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
+    for (int64_t q = 32; q <= kMaxBlock; ++q) {
+        if (2 * hw + 3 * q > (int64_t{1} << kMaxRingLog2F64)) break;
+        int64_t nd = 0;
+        for (int64_t u = -hw - q; u <= hw; ++u) nd += tap_at(u + q) != tap_at(u);
+        const int64_t block = (q + 63) / 64 * 64;
+        const double cost = static_cast<double>(nd + 6) * static_cast<double>(block) / static_cast<double>(q);
+        if (cost < best_cost - 1e-12 || (std::fabs(cost - best_cost) <= 1e-12 && q > best_q)) {
+            best_cost = cost;
+            best_q = q;
+        }
+    }
+    (void)L;
+    p->q = best_q;
+    if (best_q == 0) return;  // half-width too large for the LDS ring -> gather kernel only
+    const int64_t q = best_q;
+    std::vector<int32_t> plus, minus;
+    for (int64_t u = -hw - q; u <= hw; ++u) {
+        const int d = tap_at(u + q) - tap_at(u);
+        if (d > 0) plus.push_back(static_cast<int32_t>(u));
+        if (d < 0) minus.push_back(static_cast<int32_t>(u));
+    }
+    p->n_plus = static_cast<int64_t>(plus.size());
+    p->n_minus = static_cast<int64_t>(minus.size());
+    delta->assign(plus.begin(), plus.end());
+    delta->insert(delta->end(), minus.begin(), minus.end());
+    p->block_threads = static_cast<int>((q + 63) / 64 * 64);
+    p->ring_log2_f64 = next_pow2_log2(2 * hw + 3 * q);
+    int g = kMaxRowsPerFill;
+    while (g > 1 && 2 * hw + (2 * g + 1) * q > (int64_t{1} << p->ring_log2_f64)) g >>= 1;
+    p->rows_per_fill = g;
+}
+
+int resolve_kernel(const parrm_filter_plan *p, int64_t n_chans, int64_t out_len) {
+    if (p->forced_kernel == PARRM_KERNEL_GATHER) return PARRM_KERNEL_GATHER;
+    if (p->q == 0) return PARRM_KERNEL_GATHER;
+    if (p->forced_kernel == PARRM_KERNEL_STRIDE) return PARRM_KERNEL_STRIDE;
+    // tiny problems: the per-stretch prologue (2*hw + ... samples) would dominate
+    if (n_chans * out_len < (int64_t{1} << 15)) return PARRM_KERNEL_GATHER;
+    return PARRM_KERNEL_STRIDE;
+}
+
+template <typename TI, typename TO>
+int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
+    if (kernel == PARRM_KERNEL_GATHER) {
+        const int block = 256;
+        const int64_t gx = (a.out_len + block - 1) / block;
+        const int64_t gy = std::min<int64_t>(a.n_chans, 65535);
+        PARRM_REQUIRE(gx <= 0x7fffffffLL, "filter: too many samples for one launch");
+        hipLaunchKernelGGL((filter_gather_kernel<TI, TO>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)),
+                           dim3(block), 0, stream, a);
+        PARRM_HIP_CHECK(hipGetLastError());
+        return PARRM_OK;
+    }
+    // stride kernel geometry
+    const int q = static_cast<int>(p->q);
+    const int G = p->rows_per_fill;
+    int ring_log2 = p->ring_log2_f64;
+    a.q = q;
+    a.rows_per_fill = G;
+    a.ring_mask = (1 << ring_log2) - 1;
+    // stretch: ~64K samples, a whole number of fills; shrink while the grid would not fill the chip
+    int64_t rows = std::max<int64_t>(G, (65536 / q) / G * G);
+    auto blocks_for = [&](int64_t r) { return a.n_chans * ((a.out_len + r * q - 1) / (r * q)); };
+    while (rows > 4 * G && blocks_for(rows) < 2048) rows = std::max<int64_t>(G, (rows / 2) / G * G);
+    a.stretch_len = rows * q;
+    a.n_stretch = (a.out_len + a.stretch_len - 1) / a.stretch_len;
+    const int64_t blocks = a.n_chans * a.n_stretch;
+    PARRM_REQUIRE(blocks <= 0x7fffffffLL, "filter: too many workgroups for one launch");
+    const size_t lds = (size_t{1} << ring_log2) * sizeof(TI);
+    auto kern = filter_stride_kernel<TI, TO>;
+    PARRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(p->block_threads), lds, stream, a);
+    PARRM_HIP_CHECK(hipGetLastError());
+    return PARRM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_filter_plan **plan) {
+    PARRM_REQUIRE(h_filter && plan, "filter_plan_create: NULL argument");
+    PARRM_REQUIRE(filter_len >= 3 && (filter_len & 1), "filter_plan_create: filter length must be odd and >= 3");
+    PARRM_REQUIRE(filter_len < (int64_t{1} << 30), "filter_plan_create: filter too long");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        parrm::set_error("filter_plan_create: no HIP device is visible (there is no CPU fallback)");
+        return PARRM_ERR_NO_DEVICE;
+    }
+    const int64_t hw = (filter_len - 1) / 2;
+    std::vector<int8_t> tap(filter_len, 0);
+    int64_t n_taps = 0;
+    for (int64_t i = 0; i < filter_len; ++i) {
+        if (i == hw) continue;  // the centre carries the 1 (parrm.py:831)
+        if (h_filter[i] != 0.0) {
+            tap[i] = 1;
+            ++n_taps;
+        }
+    }
+    if (n_taps == 0) {
+        parrm::set_error("filter_plan_create: the filter has no taps");
+        return PARRM_ERR_EMPTY_FILTER;
+    }
+    auto *p = new parrm_filter_plan();
+    p->hw = hw;
+    p->n_taps = n_taps;
+    std::vector<int32_t> runs;
+    for (int64_t i = 0; i < filter_len;) {
+        if (!tap[i]) {
+            ++i;
+            continue;
+        }
+        int64_t j = i;
+        while (j + 1 < filter_len && tap[j + 1]) ++j;
+        runs.push_back(static_cast<int32_t>(i - hw));
+        runs.push_back(static_cast<int32_t>(j - hw));
+        i = j + 1;
+    }
+    p->n_runs = static_cast<int64_t>(runs.size() / 2);
+    std::vector<int32_t> tapcum(2 * hw + 2, 0);
+    for (int64_t j = 0; j < filter_len; ++j) tapcum[j + 1] = tapcum[j] + tap[j];
+    std::vector<int32_t> delta;
+    choose_stride(tap, hw, p, &delta);
+
+    std::vector<int32_t> tables(runs);
+    p->off_tapcum = static_cast<int64_t>(tables.size());
+    tables.insert(tables.end(), tapcum.begin(), tapcum.end());
+    p->off_delta = static_cast<int64_t>(tables.size());
+    tables.insert(tables.end(), delta.begin(), delta.end());
+    tables.push_back(0);
+    hipError_t e = hipGetDevice(&p->device);
+    if (e == hipSuccess) e = hipMalloc(&p->d_tables, tables.size() * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->d_tables) (void)hipFree(p->d_tables);
+        delete p;
+        return parrm::hip_fail(e, "filter_plan_create: table upload");
+    }
+    *plan = p;
+    return PARRM_OK;
+}
+
+int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
+    if (!plan) return PARRM_OK;
+    if (plan->d_tables) (void)hipFree(plan->d_tables);
+    delete plan;
+    return PARRM_OK;
+}
+
+int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_info *info) {
+    PARRM_REQUIRE(plan && info, "filter_plan_query: NULL argument");
+    info->half_width = plan->hw;
+    info->n_taps = plan->n_taps;
+    info->n_runs = plan->n_runs;
+    info->stride = plan->q;
+    info->n_delta = plan->n_plus + plan->n_minus;
+    info->ring_len = plan->q ? (int64_t{1} << plan->ring_log2_f64) : 0;
+    info->rows_per_fill = plan->rows_per_fill;
+    info->block_threads = plan->block_threads;
+    info->kernel = resolve_kernel(plan, int64_t{1} << 20, int64_t{1} << 20);
+    return PARRM_OK;
+}
+
+int parrm_filter_plan_set_kernel(parrm_filter_plan *plan, int kernel) {
+    PARRM_REQUIRE(plan, "filter_plan_set_kernel: NULL plan");
+    PARRM_REQUIRE(kernel == PARRM_KERNEL_AUTO || kernel == PARRM_KERNEL_GATHER || kernel == PARRM_KERNEL_STRIDE,
+                  "filter_plan_set_kernel: unknown kernel %d", kernel);
+    PARRM_REQUIRE(kernel != PARRM_KERNEL_STRIDE || plan->q != 0,
+                  "filter_plan_set_kernel: half-width %lld does not fit the LDS ring", (long long)plan->hw);
+    plan->forced_kernel = kernel;
+    return PARRM_OK;
+}
+
+int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, int x_dtype, void *d_y,
+                              int y_dtype, int64_t n_chans, int64_t buf_first, int64_t buf_len,
+                              int64_t out_first, int64_t out_len, int64_t n_total, int64_t ldx,
+                              int64_t ldy, void *stream) {
+    PARRM_REQUIRE(plan, "filter_apply: NULL plan");
+    PARRM_REQUIRE(n_chans >= 0 && out_len >= 0 && n_total >= 0 && buf_len >= 0, "filter_apply: negative size");
+    if (n_chans == 0 || out_len == 0) return PARRM_OK;
+    PARRM_REQUIRE(d_x && d_y, "filter_apply: NULL data pointer");
+    PARRM_REQUIRE(x_dtype == PARRM_F32 || x_dtype == PARRM_F64, "filter_apply: bad x_dtype %d", x_dtype);
+    PARRM_REQUIRE(y_dtype == PARRM_F64 || (y_dtype == PARRM_F32 && x_dtype == PARRM_F32),
+                  "filter_apply: y_dtype must be f64, or f32 for f32 input");
+    PARRM_REQUIRE(out_first >= 0 && out_first + out_len <= n_total, "filter_apply: outputs outside the recording");
+    PARRM_REQUIRE(ldx >= buf_len && ldy >= out_len, "filter_apply: row stride smaller than the row");
+    const int64_t need_lo = std::max<int64_t>(out_first - plan->hw, 0);
+    const int64_t need_hi = std::min<int64_t>(out_first + out_len + plan->hw, n_total);
+    PARRM_REQUIRE(buf_first <= need_lo && buf_first + buf_len >= need_hi,
+                  "filter_apply: window [%lld,%lld) does not cover the halo [%lld,%lld)", (long long)buf_first,
+                  (long long)(buf_first + buf_len), (long long)need_lo, (long long)need_hi);
+
+    FilterArgs a{};
+    a.x = d_x;
+    a.y = d_y;
+    a.n_chans = n_chans;
+    a.buf_first = buf_first;
+    a.buf_len = buf_len;
+    a.out_first = out_first;
+    a.out_len = out_len;
+    a.n_total = n_total;
+    a.ldx = ldx;
+    a.ldy = ldy;
+    a.runs = plan->d_tables;
+    a.tapcum = plan->d_tables + plan->off_tapcum;
+    a.delta = plan->d_tables + plan->off_delta;
+    a.n_runs = static_cast<int32_t>(plan->n_runs);
+    a.n_plus = static_cast<int32_t>(plan->n_plus);
+    a.n_minus = static_cast<int32_t>(plan->n_minus);
+    a.hw = static_cast<int32_t>(plan->hw);
+    a.n_taps = static_cast<int32_t>(plan->n_taps);
+    a.inv_taps = 1.0 / static_cast<double>(plan->n_taps);
+    const int kernel = resolve_kernel(plan, n_chans, out_len);
+    hipStream_t s = parrm::as_stream(stream);
+    if (x_dtype == PARRM_F64) return launch<double, double>(plan, a, kernel, s);
+    if (y_dtype == PARRM_F64) return launch<float, double>(plan, a, kernel, s);
+    return launch<float, float>(plan, a, kernel, s);
+}
+
+int parrm_filter_apply(const parrm_filter_plan *plan, const void *d_x, int x_dtype, void *d_y, int y_dtype,
+                       int64_t n_chans, int64_t n_samples, int64_t ldx, int64_t ldy, void *stream) {
+    return parrm_filter_apply_window(plan, d_x, x_dtype, d_y, y_dtype, n_chans, 0, n_samples, 0, n_samples,
+                                     n_samples, ldx, ldy, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,438 @@
+// find_period on gfx950: the three device stages behind parrm.py:272-280 and :552-632.
+//
+//   absdiff_*        one streaming pass: scale[c] = mean_i |x[c,i+1]-x[c,i]|        (:274-275)
+//   gather_kernel    Y[j][c] = clip((x[c,idx_j+1]-x[c,idx_j])/scale[c], +-ob)        (:274-278,:590)
+//   fit_accum_kernel per (period, sample slice): the Gram blocks  W'[Y | W]  of the harmonic
+//                    regression, W = [1, sin(k a), cos(k a)], a = (idx+1)*(2pi/T)    (:619-626)
+//   fit_reduce_kernel / fit_solve_kernel: sum the slices, LU-solve the normal equations, turn
+//                    (G, R, y'y) into the channel-averaged regularised error         (:585-597,:626-632)
+//
+// The regression is a skinny f64 contraction (K <= 47 rows, n <= 25001 samples, C+K columns), bound
+// by FP64 vector FMA + sincos issue, not by HBM: Y (<= 51 MB) stays in L2 / Infinity Cache.
+// No MFMA: FP64 matrix and vector peaks are equal on MI355X (hard part 4).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "parrm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ a3
+constexpr int kStatChunk = 32768;  // diffs per workgroup
+
+template <typename T>
+__global__ void __launch_bounds__(256) absdiff_partial_kernel(const T *x, int64_t n_samples, int64_t ldx,
+                                                               int64_t n_chunk, double *partial) {
+    const int64_t c = blockIdx.x / n_chunk;
+    const int64_t k = blockIdx.x - c * n_chunk;
+    const T *row = x + c * ldx;
+    const int64_t lo = k * kStatChunk;
+    int64_t hi = lo + kStatChunk;
+    if (hi > n_samples - 1) hi = n_samples - 1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {  // 4 independent loads in flight per lane
+        const T d0 = row[i + 1] - row[i];
+        const T d1 = row[i + 257] - row[i + 256];
+        const T d2 = row[i + 513] - row[i + 512];
+        const T d3 = row[i + 769] - row[i + 768];
+        a0 += fabs(static_cast<double>(d0));
+        a1 += fabs(static_cast<double>(d1));
+        a2 += fabs(static_cast<double>(d2));
+        a3 += fabs(static_cast<double>(d3));
+    }
+    for (; i < hi; i += 256) a0 += fabs(static_cast<double>(static_cast<T>(row[i + 1] - row[i])));
+    double v = parrm::wave_sum((a0 + a1) + (a2 + a3));
+    __shared__ double wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ void __launch_bounds__(64) absdiff_final_kernel(const double *partial, int64_t n_chunk,
+                                                            int64_t n_samples, double *scale) {
+    const int64_t c = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t k = threadIdx.x; k < n_chunk; k += 64) acc += partial[c * n_chunk + k];
+    acc = parrm::wave_sum(acc);
+    if (threadIdx.x == 0) scale[c] = acc / static_cast<double>(n_samples - 1);
+}
+
+// ------------------------------------------------------------------------------------ a3 o a4
+template <typename T>
+__global__ void __launch_bounds__(256) gather_kernel(const T *x, int64_t n_chans, int64_t ldx,
+                                                      const int64_t *idx, int64_t n_idx, const double *scale,
+                                                      double ob, double *y, int64_t ldy) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= n_idx) return;
+    const int64_t i = idx[j];
+    for (int64_t c = blockIdx.y; c < n_chans; c += gridDim.y) {
+        const T *row = x + c * ldx;
+        const T d = row[i + 1] - row[i];  // np.diff keeps the input dtype (:274)
+        const double v = static_cast<double>(d) / scale[c];             // :275
+        y[j * ldy + c] = v != v ? v : fmin(fmax(v, -ob), ob);           // :276-278 (np.clip keeps NaN)
+    }
+}
+
+// ------------------------------------------------------------------------------------ a6 / a7
+constexpr int kTJ = 16;      // samples per LDS tile
+constexpr int kYCols = 256;  // data columns per workgroup
+constexpr int kNCol = 320;   // + up to 64 columns holding W itself (-> Gram matrix)
+constexpr int kMaxBw = 23;
+
+__host__ __device__ inline int kp_for(int bw) {  // padded row count: 4 waves x KT rows
+    const int K = 2 * bw + 1;
+    return K <= 12 ? 12 : (K <= 24 ? 24 : 48);
+}
+
+// part[(((p*nz + zb)*nsplit + s)*(KP+1) + row)*kNCol + col]; row KP holds y'y per column.
+template <int KT>
+__global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t ldy, const int64_t *idx,
+                                                         int n_idx, int n_chans, const double *periods,
+                                                         int bw, int nsplit, double *part) {
+    constexpr int KP = 4 * KT;
+    __shared__ double Wt[kTJ][KP];
+    __shared__ double Yt[kTJ][kNCol];
+    const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
+    const int s = blockIdx.x, p = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
+    const int K = 2 * bw + 1;
+    const double w0 = 6.283185307179586 / periods[p];  // (2 * np.pi / period), :619
+
+    for (int it = tid; it < kTJ * KP; it += 256) Wt[it / KP][it % KP] = 0.0;
+    for (int it = tid; it < kTJ * 64; it += 256) Yt[it / 64][kYCols + (it % 64)] = 0.0;
+
+    double acc[KT][5];
+    double yy[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        yy[i] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) acc[kk][i] = 0.0;
+    }
+
+    const int tiles = (n_idx + kTJ - 1) / kTJ;
+    const int per = (tiles + nsplit - 1) / nsplit;
+    const int t_lo = s * per;
+    const int t_hi = min(tiles, t_lo + per);
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int j0 = t * kTJ;
+        for (int it = tid; it < kTJ * (bw + 1); it += 256) {
+            const int j = it % kTJ, k = it / kTJ, jj = j0 + j;
+            if (k == 0) {
+                const double one = jj < n_idx ? 1.0 : 0.0;
+                Wt[j][0] = one;
+                Yt[j][kYCols] = one;
+            } else {
+                double sn = 0.0, cs = 0.0;
+                if (jj < n_idx) {
+                    const double ang = static_cast<double>(idx[jj] + 1) * w0;  // :619
+                    sincos(static_cast<double>(k) * ang, &sn, &cs);            // :622-623
+                }
+                Wt[j][2 * k - 1] = sn;
+                Wt[j][2 * k] = cs;
+                Yt[j][kYCols + 2 * k - 1] = sn;
+                Yt[j][kYCols + 2 * k] = cs;
+            }
+        }
+        for (int it = tid; it < kTJ * kYCols; it += 256) {
+            const int j = it / kYCols, col = it % kYCols, jj = j0 + j;
+            const int gc = zb * kYCols + col;
+            Yt[j][col] = (jj < n_idx && gc < n_chans) ? Y[static_cast<int64_t>(jj) * ldy + gc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < kTJ; ++j) {
+            double w[KT], y[5];
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) w[kk] = Wt[j][kg * KT + kk];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) y[i] = Yt[j][lane + 64 * i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                yy[i] = fma(y[i], y[i], yy[i]);
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk) acc[kk][i] = fma(w[kk], y[i], acc[kk][i]);
+            }
+        }
+        __syncthreads();
+    }
+    (void)K;
+    double *out = part + ((static_cast<int64_t>(p) * nz + zb) * nsplit + s) * (KP + 1) * kNCol;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) out[(kg * KT + kk) * kNCol + lane + 64 * i] = acc[kk][i];
+    if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) out[KP * kNCol + lane + 64 * i] = yy[i];
+    }
+}
+
+// red[(p*nz+zb)][e] = sum_s part[(p*nz+zb)][s][e], s ascending (deterministic)
+__global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int nsplit, int64_t elems,
+                                                          double *red) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    const int64_t pz = blockIdx.y;
+    const double *src = part + pz * nsplit * elems + e;
+    double a = 0.0;
+    for (int s = 0; s < nsplit; ++s) a += src[s * elems];
+    red[pz * elems + e] = a;
+}
+
+// One workgroup per candidate period: LU(G) with partial pivoting, solve for every channel,
+// err = mean_c[(y'y - 2 b'R + b'G b)/n + regu . b^2].
+__global__ void __launch_bounds__(256) fit_solve_kernel(const double *red, int n_idx, int n_chans, int bw,
+                                                         int KP, int nz, double lambda, double *err) {
+    constexpr int KS = 49;   // padded row stride of the K x K matrices
+    constexpr int RS = 257;  // padded row stride of the K x 256 right-hand sides
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *A = reinterpret_cast<double *>(lds_raw);  // [K][KS] LU factors
+    double *G0 = A + 48 * KS;                         // [K][KS] original Gram matrix
+    double *Rl = G0 + 48 * KS;                        // [K][RS] rhs -> beta
+    __shared__ int piv[48];
+    __shared__ int singular;
+    __shared__ double wsum[4];
+
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const int K = 2 * bw + 1;
+    const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
+    const double *base = red + static_cast<int64_t>(p) * nz * elems;
+
+    for (int e = tid; e < K * K; e += 256) {
+        const int r = e / K, c = e % K;
+        const double g = base[r * kNCol + kYCols + c];
+        A[r * KS + c] = g;
+        G0[r * KS + c] = g;
+    }
+    if (tid == 0) singular = 0;
+    __syncthreads();
+
+    for (int col = 0; col < K; ++col) {
+        if (tid < 64) {  // idamax over rows col..K-1 (first maximum wins, like LAPACK)
+            const int r = col + tid;
+            double v = r < K ? fabs(A[r * KS + col]) : -1.0;
+            if (v != v) v = 1e308;  // a NaN column: let it through as the pivot, like a NaN compare chain
+            int best = r;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(v, off, 64);
+                const int ob = __shfl_xor(best, off, 64);
+                if (ov > v || (ov == v && ob < best)) {
+                    v = ov;
+                    best = ob;
+                }
+            }
+            if (tid == 0) piv[col] = best;
+        }
+        __syncthreads();
+        const int pr = piv[col];
+        if (pr != col && tid < K) {
+            const double tmp = A[col * KS + tid];
+            A[col * KS + tid] = A[pr * KS + tid];
+            A[pr * KS + tid] = tmp;
+        }
+        __syncthreads();
+        const double pv = A[col * KS + col];
+        if (pv == 0.0) {  // exactly singular: numpy raises LinAlgError -> inf (:627-628)
+            if (tid == 0) singular = 1;
+            break;  // pv is uniform across the workgroup
+        }
+        if (tid > col && tid < K) A[tid * KS + col] /= pv;
+        __syncthreads();
+        const int m = K - col - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = col + 1 + e / m, j = col + 1 + e % m;
+            A[i * KS + j] -= A[i * KS + col] * A[col * KS + j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (singular) {
+        if (tid == 0) err[p] = INFINITY;
+        return;
+    }
+
+    const double ksum = static_cast<double>(K * (K + 1) / 2);
+    double total = 0.0;
+    for (int zb = 0; zb < nz; ++zb) {
+        const double *rz = base + zb * elems;
+        const int ncol = min(kYCols, n_chans - zb * kYCols);
+        for (int e = tid; e < K * kYCols; e += 256) {
+            const int r = e / kYCols, c = e % kYCols;
+            Rl[r * RS + c] = c < ncol ? rz[r * kNCol + c] : 0.0;
+        }
+        __syncthreads();
+        double e_c = 0.0;
+        if (tid < ncol) {
+            double *b = Rl + tid;
+            for (int i = 0; i < K; ++i) {  // apply the row interchanges
+                const int pr = piv[i];
+                if (pr != i) {
+                    const double tmp = b[i * RS];
+                    b[i * RS] = b[pr * RS];
+                    b[pr * RS] = tmp;
+                }
+            }
+            for (int i = 1; i < K; ++i) {  // L z = P r
+                double v = b[i * RS];
+                for (int j = 0; j < i; ++j) v -= A[i * KS + j] * b[j * RS];
+                b[i * RS] = v;
+            }
+            for (int i = K - 1; i >= 0; --i) {  // U beta = z
+                double v = b[i * RS];
+                for (int j = i + 1; j < K; ++j) v -= A[i * KS + j] * b[j * RS];
+                b[i * RS] = v / A[i * KS + i];
+            }
+            double t1 = 0.0, t2 = 0.0, reg = 0.0;
+            for (int i = 0; i < K; ++i) {
+                const double bi = b[i * RS];
+                t1 = fma(bi, rz[i * kNCol + tid], t1);
+                double gb = 0.0;
+                for (int j = 0; j < K; ++j) gb = fma(G0[i * KS + j], b[j * RS], gb);
+                t2 = fma(bi, gb, t2);
+                reg += (lambda * static_cast<double>(i + 1) / ksum) * (bi * bi);  // :585-586,:595
+            }
+            const double yy = rz[KP * kNCol + tid];
+            e_c = (yy - 2.0 * t1 + t2) / static_cast<double>(n_idx) + reg;
+        }
+        const double v = parrm::wave_sum(e_c);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = v;
+        __syncthreads();
+        total += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        __syncthreads();
+    }
+    if (tid == 0) err[p] = total / static_cast<double>(n_chans);  // :597
+}
+
+struct FitGeom {
+    int KP, nz, nsplit;
+    int64_t elems;       // (KP+1)*kNCol
+    size_t part_bytes;   // all partial Gram blocks
+    size_t red_bytes;    // reduced blocks (0 when nsplit == 1: part is used in place)
+};
+
+FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) {
+    FitGeom g{};
+    g.KP = kp_for(bw);
+    g.nz = static_cast<int>((n_chans + kYCols - 1) / kYCols);
+    const int64_t tiles = (n_idx + kTJ - 1) / kTJ;
+    // aim for >= ~1024 workgroups in flight; never split below 4 tiles per workgroup
+    int64_t want = (1024 + n_periods * g.nz - 1) / (n_periods * g.nz);
+    want = std::max<int64_t>(1, std::min<int64_t>(want, (tiles + 3) / 4));
+    g.nsplit = static_cast<int>(want);
+    g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
+    g.part_bytes = static_cast<size_t>(n_periods) * g.nz * g.nsplit * g.elems * sizeof(double);
+    g.red_bytes = g.nsplit > 1 ? static_cast<size_t>(n_periods) * g.nz * g.elems * sizeof(double) : 0;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t parrm_absdiff_workspace_bytes(int64_t n_chans, int64_t n_samples) {
+    if (n_chans <= 0 || n_samples <= 1) return sizeof(double);
+    const int64_t n_chunk = (n_samples - 1 + kStatChunk - 1) / kStatChunk;
+    return static_cast<size_t>(n_chans * n_chunk) * sizeof(double);
+}
+
+int parrm_absdiff_mean(const void *d_x, int x_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
+                       double *d_scale, void *d_workspace, size_t workspace_bytes, void *stream) {
+    PARRM_REQUIRE(d_x && d_scale && d_workspace, "absdiff_mean: NULL argument");
+    PARRM_REQUIRE(x_dtype == PARRM_F32 || x_dtype == PARRM_F64, "absdiff_mean: bad dtype %d", x_dtype);
+    PARRM_REQUIRE(n_chans > 0 && n_samples >= 2 && ldx >= n_samples, "absdiff_mean: bad shape");
+    if (workspace_bytes < parrm_absdiff_workspace_bytes(n_chans, n_samples)) {
+        parrm::set_error("absdiff_mean: workspace too small");
+        return PARRM_ERR_WORKSPACE;
+    }
+    const int64_t n_chunk = (n_samples - 1 + kStatChunk - 1) / kStatChunk;
+    const int64_t blocks = n_chans * n_chunk;
+    PARRM_REQUIRE(blocks <= 0x7fffffffLL, "absdiff_mean: recording too large for one launch");
+    double *partial = static_cast<double *>(d_workspace);
+    hipStream_t s = parrm::as_stream(stream);
+    if (x_dtype == PARRM_F64)
+        hipLaunchKernelGGL(absdiff_partial_kernel<double>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                           static_cast<const double *>(d_x), n_samples, ldx, n_chunk, partial);
+    else
+        hipLaunchKernelGGL(absdiff_partial_kernel<float>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                           static_cast<const float *>(d_x), n_samples, ldx, n_chunk, partial);
+    PARRM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(absdiff_final_kernel, dim3(static_cast<unsigned>(n_chans)), dim3(64), 0, s, partial, n_chunk,
+                       n_samples, d_scale);
+    PARRM_HIP_CHECK(hipGetLastError());
+    return PARRM_OK;
+}
+
+int parrm_gather_standardise(const void *d_x, int x_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
+                             const int64_t *d_idx, int64_t n_idx, const double *d_scale,
+                             double outlier_boundary, double *d_y, int64_t ldy, void *stream) {
+    PARRM_REQUIRE(d_x && d_idx && d_scale && d_y, "gather_standardise: NULL argument");
+    PARRM_REQUIRE(x_dtype == PARRM_F32 || x_dtype == PARRM_F64, "gather_standardise: bad dtype %d", x_dtype);
+    PARRM_REQUIRE(n_chans > 0 && n_samples >= 2 && n_idx > 0 && ldy >= n_chans && ldx >= n_samples,
+                  "gather_standardise: bad shape");
+    const dim3 grid(static_cast<unsigned>((n_idx + 255) / 256), static_cast<unsigned>(std::min<int64_t>(n_chans, 65535)));
+    hipStream_t s = parrm::as_stream(stream);
+    if (x_dtype == PARRM_F64)
+        hipLaunchKernelGGL(gather_kernel<double>, grid, dim3(256), 0, s, static_cast<const double *>(d_x), n_chans,
+                           ldx, d_idx, n_idx, d_scale, outlier_boundary, d_y, ldy);
+    else
+        hipLaunchKernelGGL(gather_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(d_x), n_chans,
+                           ldx, d_idx, n_idx, d_scale, outlier_boundary, d_y, ldy);
+    PARRM_HIP_CHECK(hipGetLastError());
+    return PARRM_OK;
+}
+
+size_t parrm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) {
+    if (n_idx <= 0 || n_chans <= 0 || n_periods <= 0 || bw < 0 || bw > kMaxBw) return 0;
+    const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw);
+    return g.part_bytes + g.red_bytes;
+}
+
+int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
+                     const double *d_periods, int64_t n_periods, int bw, double lambda, double *d_err,
+                     void *d_workspace, size_t workspace_bytes, void *stream) {
+    PARRM_REQUIRE(d_y && d_idx && d_periods && d_err && d_workspace, "fit_errors: NULL argument");
+    PARRM_REQUIRE(bw >= 0 && bw <= kMaxBw, "fit_errors: bandwidth %d outside [0, %d]", bw, kMaxBw);
+    PARRM_REQUIRE(n_idx > 0 && n_idx < (int64_t{1} << 30) && n_chans > 0 && n_chans < (int64_t{1} << 24) &&
+                      ldy >= n_chans,
+                  "fit_errors: bad shape");
+    PARRM_REQUIRE(n_periods > 0 && n_periods <= 65535, "fit_errors: 1..65535 periods per call");
+    const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw);
+    if (workspace_bytes < g.part_bytes + g.red_bytes) {
+        parrm::set_error("fit_errors: workspace too small (%zu < %zu)", workspace_bytes, g.part_bytes + g.red_bytes);
+        return PARRM_ERR_WORKSPACE;
+    }
+    PARRM_REQUIRE(g.nz <= 65535, "fit_errors: too many channels");
+    hipStream_t s = parrm::as_stream(stream);
+    double *part = static_cast<double *>(d_workspace);
+    double *red = g.nsplit > 1 ? part + g.part_bytes / sizeof(double) : part;
+    const dim3 grid(g.nsplit, static_cast<unsigned>(n_periods), g.nz);
+    const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans);
+    if (g.KP == 12)
+        hipLaunchKernelGGL(fit_accum_kernel<3>, grid, dim3(256), 0, s, d_y, ldy, d_idx, n, C, d_periods, bw, g.nsplit, part);
+    else if (g.KP == 24)
+        hipLaunchKernelGGL(fit_accum_kernel<6>, grid, dim3(256), 0, s, d_y, ldy, d_idx, n, C, d_periods, bw, g.nsplit, part);
+    else
+        hipLaunchKernelGGL(fit_accum_kernel<12>, grid, dim3(256), 0, s, d_y, ldy, d_idx, n, C, d_periods, bw, g.nsplit, part);
+    PARRM_HIP_CHECK(hipGetLastError());
+    if (g.nsplit > 1) {
+        const dim3 rgrid(static_cast<unsigned>((g.elems + 255) / 256), static_cast<unsigned>(n_periods * g.nz));
+        PARRM_REQUIRE(n_periods * g.nz <= 65535, "fit_errors: periods x column blocks too large");
+        hipLaunchKernelGGL(fit_reduce_kernel, rgrid, dim3(256), 0, s, part, g.nsplit, g.elems, red);
+        PARRM_HIP_CHECK(hipGetLastError());
+    }
+    const size_t lds = (2 * 48 * 49 + 48 * 257) * sizeof(double);
+    PARRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fit_solve_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(fit_solve_kernel, dim3(static_cast<unsigned>(n_periods)), dim3(256), lds, s, red, n, C, bw,
+                       g.KP, g.nz, lambda, d_err);
+    PARRM_HIP_CHECK(hipGetLastError());
+    return PARRM_OK;
+}
+
+}  // extern "C"

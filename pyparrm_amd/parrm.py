@@ -1,0 +1,534 @@
+"""``PARRM`` façade: PyPARRM's class surface over the MI355X engine.
+
+Mirrors ``pyparrm.PARRM`` (reference ``src/pyparrm/parrm.py:18-936``): same constructor and
+method signatures, same validation order and messages (they are the behavioural contract the
+reference tests pin, ``tests/test_parrm.py:112-330``), same call-order state machine, same
+``settings`` layout.  What differs is where the arithmetic runs:
+
+* ``find_period``  -> device: statistics pass, column gather, batched harmonic-regression
+  objective (``parrm_absdiff_mean`` / ``parrm_gather_standardise`` / ``parrm_fit_errors``); host:
+  index draws, candidate grids and ``scipy.optimize.fmin`` exactly as the reference calls them.
+* ``create_filter`` -> host (microseconds; the tap set is a step function of the period, so it is
+  built with the same NumPy expressions to stay bit-identical, parrm.py:803-833).
+* ``filter_data``  -> device: closed-form phase-neighbour stencil (``parrm_filter_apply``).
+
+There is no CPU fallback: without the HIP library and a GPU, ``find_period`` / ``filter_data``
+raise.  Extension over the reference (additive): ``data`` may be a 2-D CUDA ``torch.Tensor``
+(results then stay on the device).
+"""
+
+from __future__ import annotations
+
+from multiprocessing import cpu_count
+
+import numpy as np
+from scipy.optimize import fmin
+
+from . import _hip
+
+_PERIOD_FAILURE = (
+    "The period cannot be estimated from the data. Check that your data "
+    "does not contain infs or NaNs."
+)
+_NO_PERIOD = (
+    "The period has not yet been estimated. The `find_period` method must be called first."
+)
+_DIRECTIONS = ["both", "past", "future"]
+
+# stage schedule of the period search (parrm.py:288-296)
+_STAGE_LENGTHS = (5000, 10000, 25000)
+_STAGE_IGNORE = (0.0, 0.0, 0.95)
+_STAGE_BANDWIDTHS = (5, 10, 20)
+_STAGE_LAMBDA = 1.0
+# above this size a host recording is streamed through the device instead of cached on it
+_DEVICE_CACHE_BYTES = 96 << 30
+
+
+def _is_number(value) -> bool:
+    return isinstance(value, (int, float))
+
+
+def _is_device_tensor(value) -> bool:
+    mod = type(value).__module__
+    return mod.startswith("torch") and hasattr(value, "is_cuda") and bool(value.is_cuda)
+
+
+class PARRM:
+    """Remove periodic stimulation artefacts with PARRM (Dastin-van Rijn et al., 2021).
+
+    Call order: :meth:`find_period` -> :meth:`create_filter` -> :meth:`filter_data`.
+
+    Parameters
+    ----------
+    data : numpy.ndarray, shape of [channels, times]
+        Recording to clean.  (Extension: a 2-D CUDA ``torch.Tensor`` is accepted too.)
+    sampling_freq : int | float
+        Sampling frequency of ``data`` in Hz.
+    artefact_freq : int | float
+        Stimulation frequency in Hz.
+    verbose : bool (default True)
+        Print progress messages.
+    """
+
+    _data = None
+    _standard_data = None
+    _filtered_data = None
+    _sampling_freq = None
+    _artefact_freq = None
+    _verbose = None
+    _period = None
+    _search_samples = None
+    _assumed_periods = None
+    _outlier_boundary = None
+    _random_seed = None
+    _n_jobs = None
+    _filter = None
+    _filter_half_width = None
+    _omit_n_samples = None
+    _filter_direction = None
+    _period_half_width = None
+
+    # ------------------------------------------------------------------ construction (a1)
+    def __init__(self, data, sampling_freq, artefact_freq, verbose=True) -> None:
+        self._check_init_inputs(data, sampling_freq, artefact_freq, verbose)
+        self._n_chans, self._n_samples = (int(s) for s in self._data.shape)
+        self._d_data = None  # device copy of a host recording (lazy)
+        self._d_scale = None
+        self._plan = None
+        self._trace = None
+
+    def _check_init_inputs(self, data, sampling_freq, artefact_freq, verbose) -> None:
+        """parrm.py:112-140 (first failing check wins)."""
+        if not isinstance(data, np.ndarray) and not _is_device_tensor(data):
+            raise TypeError("`data` must be a NumPy array.")
+        if data.ndim != 2:
+            raise ValueError("`data` must be a 2D array.")
+        self._data = data  # held by reference, never mutated (parrm.py:124)
+        for name, value in (("sampling_freq", sampling_freq), ("artefact_freq", artefact_freq)):
+            if not _is_number(value):
+                raise TypeError(f"`{name}` must be an int or a float.")
+            if value <= 0:
+                raise ValueError(f"`{name}` must be > 0.")
+            setattr(self, f"_{name}", value)
+        if not isinstance(verbose, bool):
+            raise TypeError("`verbose` must be a bool.")
+        self._verbose = verbose
+
+    def __repr__(self) -> str:
+        return (
+            f"PARRM object | Data: ({self._n_chans} channels x "
+            f"{self._n_samples} times) | Period: {self._period:.4f}"
+        )
+
+    def _say(self, text: str) -> None:
+        if self._verbose:
+            print(text)
+
+    # ------------------------------------------------------------------ device residency
+    def _device_recording(self, data=None):
+        """Float device tensor [C, N] for ``data`` (default: the object's own recording)."""
+        torch = _hip.require_gpu()
+        own = data is None or data is self._data
+        src = self._data if own else data
+        if _is_device_tensor(src):
+            t = src
+            if t.dtype not in (torch.float32, torch.float64):
+                t = t.to(torch.float64)
+            return t if t.stride(-1) == 1 else t.contiguous()
+        if own and self._d_data is not None:
+            return self._d_data
+        host = src
+        if host.dtype not in (np.float32, np.float64):
+            host = host.astype(np.float64)  # the reference promotes through float64 arithmetic
+        t = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+        if own:
+            self._d_data = t
+        return t
+
+    def release_device_cache(self) -> None:
+        """Drop the cached device copy of a host recording (e.g. after mutating ``data``)."""
+        self._d_data = None
+        self._d_scale = None
+
+    # ------------------------------------------------------------------ find_period (a2-a8)
+    def find_period(
+        self,
+        search_samples=None,
+        assumed_periods=None,
+        outlier_boundary=3.0,
+        random_seed=None,
+        n_jobs=1,
+    ) -> None:
+        """Estimate the artefact period (reference: parrm.py:148-194).
+
+        ``n_jobs`` is validated as in the reference but not used: candidate periods are
+        evaluated as one device batch instead of a thread-pool map.
+        """
+        self._say("\nFinding the artefact period...")
+        self._reset_result_attrs()
+        self._check_sort_find_stim_period_inputs(
+            search_samples, assumed_periods, outlier_boundary, random_seed, n_jobs
+        )
+        self._standardise_data()
+        self._optimise_period_estimate()
+        self._say("    ... Artefact period found\n")
+
+    def _reset_result_attrs(self) -> None:
+        """parrm.py:196-211: a new search invalidates everything downstream (not ``_n_jobs``)."""
+        for name in (
+            "_standard_data", "_filtered_data", "_period", "_search_samples", "_assumed_periods",
+            "_outlier_boundary", "_random_seed", "_filter", "_filter_half_width",
+            "_omit_n_samples", "_filter_direction", "_period_half_width",
+        ):
+            setattr(self, name, None)
+        self._plan = None
+        self._d_scale = None
+
+    def _check_sort_find_stim_period_inputs(
+        self, search_samples, assumed_periods, outlier_boundary, random_seed, n_jobs
+    ) -> None:
+        """parrm.py:213-270."""
+        if search_samples is not None and not isinstance(search_samples, np.ndarray):
+            raise TypeError("`search_samples` must be a NumPy array or None.")
+        if search_samples is None:
+            search_samples = np.arange(self._n_samples - 1)
+        elif search_samples.ndim != 1:
+            raise ValueError("`search_samples` must be a 1D array.")
+        search_samples = np.sort(search_samples)
+        if search_samples[0] < 0 or search_samples[-1] >= self._n_samples:
+            raise ValueError("Entries of `search_samples` must lie in the range [0, n_samples).")
+        self._search_samples = search_samples
+
+        if assumed_periods is not None and not isinstance(assumed_periods, (int, float, tuple)):
+            raise TypeError("`assumed_periods` must be an int, a float, a tuple, or None.")
+        if assumed_periods is None:
+            assumed_periods = (self._sampling_freq / self._artefact_freq,)
+        elif _is_number(assumed_periods):
+            assumed_periods = (assumed_periods,)
+        elif not all(_is_number(entry) for entry in assumed_periods):
+            raise TypeError("If a tuple, entries of `assumed_periods` must be ints or floats.")
+        self._assumed_periods = assumed_periods
+
+        if not _is_number(outlier_boundary):
+            raise TypeError("`outlier_boundary` must be an int or a float.")
+        if outlier_boundary <= 0:
+            raise ValueError("`outlier_boundary` must be > 0.")
+        self._outlier_boundary = outlier_boundary
+
+        if random_seed is not None and not isinstance(random_seed, int):
+            raise TypeError("`random_seed` must be an int or None.")
+        if random_seed is not None:
+            self._random_seed = random_seed
+
+        self._n_jobs = _checked_n_jobs(n_jobs)
+
+    def _standardise_data(self) -> None:
+        """Device statistics pass for parrm.py:272-280.
+
+        Only ``scale[c] = mean|diff|`` is produced (one HBM read of the recording); the
+        standardised array itself is never materialised -- each stage gathers and scales the
+        <= 25 001 columns it consumes (``_stage_matrix``)."""
+        x = self._device_recording()
+        if x.shape[1] < 2:
+            raise ValueError("`data` must have at least 2 samples to estimate a period.")
+        kind = getattr(self._data, "dtype", None)
+        if isinstance(self._data, np.ndarray) and kind is not None and not np.issubdtype(kind, np.floating):
+            # the reference's in-place divide raises for integer recordings (parrm.py:275)
+            raise TypeError("`data` must have a floating-point dtype to estimate the period.")
+        self._d_scale = _hip.absdiff_mean(x)
+
+    def _stage_matrix(self, indices: np.ndarray):
+        torch = _hip.require_gpu()
+        x = self._device_recording()
+        if indices.shape[0] == 0 or indices[0] < 0 or indices[-1] >= self._n_samples - 1:
+            raise IndexError("period-search sample indices fall outside the differenced recording")
+        d_idx = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64)).to(x.device)
+        y = _hip.gather_standardise(x, d_idx, self._d_scale, self._outlier_boundary)
+        return y, d_idx
+
+    def _optimise_period_estimate(self) -> None:
+        """Three coarse-to-fine stages + an un-regularised polish (parrm.py:282-325)."""
+        rng = np.random.default_rng(self._random_seed)
+        estimate = self._assumed_periods
+        lengths = np.unique(
+            [int(np.min((self._search_samples.shape[0], n))) for n in _STAGE_LENGTHS]
+        )
+        ws = _hip.FitWorkspace()
+        trace = []
+        stage = None
+        for run, (use_n, ignore, bandwidth) in enumerate(
+            zip(lengths, _STAGE_IGNORE, _STAGE_BANDWIDTHS), start=1
+        ):
+            indices = self._get_centre_indices(use_n, ignore, rng)
+            bandwidth = int(np.min((bandwidth, indices.shape[0] // 4)))
+            y, d_idx = self._stage_matrix(indices)
+            stage = (y, d_idx)
+
+            def objective(period, _y=y, _i=d_idx, _bw=bandwidth):
+                # `period` is a float64 scalar (grid) or a shape-(1,) array (fmin), parrm.py:578-581
+                return float(_hip.fit_errors(_y, _i, np.asarray(period), _bw, _STAGE_LAMBDA, ws)[0])
+
+            grid = self._get_possible_periods(estimate, run)
+            errors = _hip.fit_errors(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, ws)
+            ranked, ranked_errors = _rank_candidates(grid, errors)
+            estimate = _refine_candidates(ranked, ranked_errors, objective)
+            trace.append(
+                {"indices": indices, "bandwidth": bandwidth, "grid": grid, "errors": errors,
+                 "estimate": float(estimate[0])}
+            )
+        if not np.isfinite(estimate[0]):
+            raise ValueError(_PERIOD_FAILURE)
+
+        # final polish: lambda = 0, bandwidth 20 *unclipped*, last stage's indices (parrm.py:524-550)
+        y, d_idx = stage
+        final_bw = _STAGE_BANDWIDTHS[-1]
+
+        def final_objective(period):
+            return float(_hip.fit_errors(y, d_idx, np.asarray(period), final_bw, 0.0, ws)[0])
+
+        self._period = fmin(final_objective, estimate[0], disp=False)[0]
+        self._trace = trace
+
+    def _get_centre_indices(self, use_n_samples, ignore_portion, random_state) -> np.ndarray:
+        """Sample indices for one stage (parrm.py:327-374): a contiguous centre block, or -- when
+        the block would not exceed ``ignore_portion`` of the recording -- unique random draws
+        from the central part.  Kept on the host so the PCG64 draws are the reference's."""
+        first, last = self._search_samples[0], self._search_samples[-1]
+        centre2 = first + last
+        lo = int(np.ceil((centre2 - use_n_samples) / 2))
+        hi = int(np.floor((centre2 + use_n_samples) / 2))
+        if self._n_samples * ignore_portion < hi - lo:
+            return np.arange(lo, hi + 1)
+        margin = (1.0 - ignore_portion) / 2.0 * self._n_samples
+        lo = int(first + np.floor(margin))
+        hi = int(last - np.ceil(margin))
+        draws = random_state.integers(0, hi - lo, np.min((use_n_samples, hi - lo)))
+        return np.unique(draws) + lo
+
+    @staticmethod
+    def _get_possible_periods(estimated_period, run: int) -> np.ndarray:
+        """Candidate grid (parrm.py:376-405): +-1 % in 1e-4 steps and +-0.1 % in 1e-5 steps
+        around every estimate, both shrunk by ``run``; 1-ulp near-duplicates survive ``unique``."""
+        rel = np.concatenate(
+            (
+                1 + np.arange(-1e-2, 1e-2 + 1e-4, 1e-4) / run,
+                1 + np.arange(-1e-3, 1e-3 + 1e-5, 1e-5) / run,
+            )
+        )
+        candidates = []
+        for estimate in estimated_period:
+            candidates.extend(estimate * rel)
+        return np.unique(candidates)
+
+    # ------------------------------------------------------------------ explorer (out of scope)
+    def explore_filter_params(self, time_range=None, time_res=0.01, freq_range=None, freq_res=5.0,
+                              n_jobs=1) -> None:
+        """Interactive parameter explorer (parrm.py:634-687): GUI, outside this engine's scope
+        (SURVEY.md section 8f-1).  The call-order check is kept."""
+        self._say("Opening the filter parameter explorer...")
+        if self._period is None:
+            raise ValueError(_NO_PERIOD)
+        raise NotImplementedError(
+            "explore_filter_params is a matplotlib GUI of the reference and is not part of the "
+            "MI355X hot path; create_filter()/filter_data() can be called repeatedly instead."
+        )
+
+    # ------------------------------------------------------------------ create_filter (a9, a10)
+    def create_filter(self, filter_half_width=None, omit_n_samples=0, filter_direction="both",
+                      period_half_width=None) -> None:
+        """Design the PARRM filter (reference: parrm.py:689-737)."""
+        self._say("Creating the filter...")
+        if self._period is None:
+            raise ValueError(_NO_PERIOD)
+        self._check_sort_create_filter_inputs(
+            filter_half_width, omit_n_samples, filter_direction, period_half_width
+        )
+        self._generate_filter()
+        self._say("    ... Filter created\n")
+
+    def _check_sort_create_filter_inputs(self, filter_half_width, omit_n_samples, filter_direction,
+                                         period_half_width) -> None:
+        """parrm.py:739-786; order: omit -> period half-width -> half-width -> direction."""
+        half_max = (self._n_samples - 1) // 2
+        if not isinstance(omit_n_samples, int):
+            raise TypeError("`omit_n_samples` must be an int.")
+        if omit_n_samples < 0 or omit_n_samples >= half_max:
+            raise ValueError("`omit_n_samples` must lie in the range [0, (no. of samples - 1) // 2).")
+        self._omit_n_samples = omit_n_samples
+
+        if period_half_width is None:
+            period_half_width = self._period / 50
+        if not _is_number(period_half_width):
+            raise TypeError("`period_half_width` must be an int or a float.")
+        if period_half_width <= 0 or period_half_width > self._period:
+            raise ValueError("`period_half_width` must be lie in the range (0, period].")
+        self._period_half_width = period_half_width
+
+        if filter_half_width is None:  # needs the two settings above
+            filter_half_width = self._get_filter_half_width()
+        if not isinstance(filter_half_width, int):
+            raise TypeError("`filter_half_width` must be an int.")
+        if filter_half_width <= omit_n_samples or filter_half_width > half_max:
+            raise ValueError(
+                "`filter_half_width` must lie in the range (`omit_n_samples`, "
+                "(no. of samples - 1) // 2]."
+            )
+        self._filter_half_width = filter_half_width
+
+        if not isinstance(filter_direction, str):
+            raise TypeError("`filter_direction` must be a str.")
+        if filter_direction not in _DIRECTIONS:
+            raise ValueError(f"`filter_direction` must be one of {_DIRECTIONS}.")
+        self._filter_direction = filter_direction
+
+    def _get_filter_half_width(self) -> int:
+        """Smallest half-width covering 50 in-phase offsets beyond the omitted centre, capped at
+        (N-1)//2 (parrm.py:788-801; the `>= period + half-width` clause there never fires)."""
+        limit = (self._n_samples - 1) // 2
+        width, hits = self._omit_n_samples, 0
+        while hits < 50 and width < limit:
+            width += 1
+            phase = np.mod(width, self._period)
+            hits += bool(
+                phase <= self._period_half_width or phase >= self._period + self._period_half_width
+            )
+        return width
+
+    def _generate_filter(self) -> None:
+        """Dense filter array (parrm.py:803-833): 1 at the centre, -1/S on every offset whose
+        phase is within ``period_half_width`` of the centre's, 0 elsewhere."""
+        hw, period, phw = self._filter_half_width, self._period, self._period_half_width
+        offsets = np.arange(-hw, hw + 1)
+        phase = np.mod(offsets, period)
+        chosen = ((phase <= phw) | (phase >= period - phw)) & (np.abs(offsets) > self._omit_n_samples)
+        if self._filter_direction == "past":
+            chosen &= offsets <= 0
+        elif self._filter_direction == "future":
+            chosen &= offsets > 0
+        n_taps = int(np.count_nonzero(chosen))
+        if n_taps == 0:
+            raise RuntimeError(
+                "A suitable filter cannot be created with the specified settings. Try "
+                "reducing the number of omitted samples and/or increasing the filter "
+                "half-width."
+            )
+        taps = np.zeros(offsets.shape, dtype=np.float64)
+        taps[chosen] = 1.0
+        taps = -taps / np.max((taps.sum(), np.finfo(np.float64).eps))
+        taps[hw] = 1
+        self._filter = taps
+        self._plan = None  # device tables are rebuilt lazily for the new taps
+
+    # ------------------------------------------------------------------ filter_data (a11)
+    def filter_data(self, data=None):
+        """Apply the filter (reference: parrm.py:835-875) and return the cleaned recording.
+
+        float64 out for any input dtype (the reference's rule).  NumPy in -> NumPy out; a CUDA
+        tensor in -> CUDA tensor out.  The result is also kept as ``filtered_data``.
+        """
+        self._say("Filtering the data...")
+        if self._filter is None:
+            raise ValueError(
+                "The filter has not yet been created. The `create_filter` method must "
+                "be called first."
+            )
+        data = self._check_sort_filter_data_inputs(data)
+        if self._plan is None:
+            self._plan = _hip.FilterPlan(self._filter)
+        if isinstance(data, np.ndarray) and data.nbytes > _DEVICE_CACHE_BYTES:
+            filtered = self._plan.apply_host(data)
+        else:
+            y = self._plan.apply(self._device_recording(data))
+            filtered = y.cpu().numpy() if isinstance(data, np.ndarray) else y
+        self._filtered_data = filtered
+        self._say("    ... Data filtered\n")
+        return self._filtered_data
+
+    def _check_sort_filter_data_inputs(self, data):
+        """parrm.py:877-886."""
+        if data is None:
+            data = self._data
+        if not isinstance(data, np.ndarray) and not _is_device_tensor(data):
+            raise TypeError("`data` must be a NumPy array.")
+        if data.ndim != 2:
+            raise ValueError("`data` must be a 2D array.")
+        return data
+
+    # ------------------------------------------------------------------ properties (a12)
+    @property
+    def data(self):
+        """The original recording."""
+        return self._data
+
+    @property
+    def period(self):
+        """The estimated artefact period, in samples."""
+        if self._period is None:
+            raise AttributeError("No period has been computed yet.")
+        return self._period
+
+    @property
+    def filter(self) -> np.ndarray:
+        """The PARRM filter (the internal array, not a copy)."""
+        if self._filter is None:
+            raise AttributeError("No filter has been computed yet.")
+        return self._filter
+
+    @property
+    def filtered_data(self):
+        """The most recently filtered recording."""
+        if self._filtered_data is None:
+            raise AttributeError("No data has been filtered yet.")
+        return self._filtered_data
+
+    @property
+    def settings(self) -> dict:
+        """Settings behind the current filter (layout of parrm.py:914-936)."""
+        if self._period is None or self._filter is None:
+            raise AttributeError("Analysis settings have not been established yet.")
+        return {
+            "data": {"sampling_freq": self._sampling_freq, "artefact_freq": self._artefact_freq},
+            "period": {
+                "search_samples": self._search_samples,
+                "assumed_periods": self._assumed_periods,
+                "outlier_boundary": self._outlier_boundary,
+                "random_seed": self._random_seed,
+            },
+            "filter": {
+                "filter_half_width": self._filter_half_width,
+                "omit_n_samples": self._omit_n_samples,
+                "filter_direction": self._filter_direction,
+                "period_half_width": self._period_half_width,
+            },
+        }
+
+
+def _checked_n_jobs(n_jobs) -> int:
+    """parrm.py:262-270."""
+    if not isinstance(n_jobs, int):
+        raise TypeError("`n_jobs` must be an int.")
+    if n_jobs > cpu_count():
+        raise ValueError("`n_jobs` must be <= the number of available CPUs.")
+    if n_jobs <= 0 and n_jobs != -1:
+        raise ValueError("If `n_jobs` is <= 0, it must be -1.")
+    return cpu_count() if n_jobs == -1 else n_jobs
+
+
+def _rank_candidates(periods: np.ndarray, errors: np.ndarray):
+    """Sort candidates by error and drop the non-finite ones (parrm.py:456-465)."""
+    order = errors.argsort()
+    errors = errors[order]
+    periods = periods[order[np.isfinite(errors)]]
+    if periods.shape == (0,):
+        raise ValueError(_PERIOD_FAILURE)
+    return periods, errors
+
+
+def _refine_candidates(periods: np.ndarray, errors: np.ndarray, objective) -> tuple:
+    """Nelder-Mead (SciPy defaults) from the best <= 5 candidates; keep the overall arg-min
+    (parrm.py:467-522).  ``errors`` may be longer than ``periods`` (non-finite tail)."""
+    for i in range(int(np.min((5, periods.shape[0])))):
+        xopt, fopt = fmin(objective, periods[i], full_output=True, disp=False)[:2]
+        periods[i] = xopt[0]
+        errors[i] = fopt
+    return (periods[errors.argmin()],)

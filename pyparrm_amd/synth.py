@@ -1,0 +1,69 @@
+"""Synthetic DBS-like recordings (the generator SURVEY.md section 8d defines; the reference
+ships none -- its tests use white noise, tests/test_parrm.py:30-31).
+
+x[c, n] = s[c, n] + g_c * A((n + phi_c) mod T*),  T* = fs / f_art * (1 + detune)
+  s    unit-variance Gaussian background, per-channel stream
+  A    20 harmonics of the period with 1/k amplitudes and fixed phases
+  g_c  in [5, 20], phi_c in [0, T*)
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+N_HARMONICS = 20
+
+
+def _artefact_params(n_chans: int, period: float):
+    phases = np.random.default_rng(7).uniform(0.0, 2.0 * np.pi, N_HARMONICS)
+    r = np.random.default_rng(8)
+    gains = r.uniform(5.0, 20.0, n_chans)
+    offsets = r.uniform(0.0, period, n_chans)
+    return phases, gains, offsets
+
+
+def synth_recording(n_chans: int, n_samples: int, sampling_freq: float, artefact_freq: float,
+                    seed: int = 0, detune: float = 3e-5, dtype=np.float64) -> np.ndarray:
+    """Host (NumPy) recording, channel c seeded with ``1000 + seed + c``."""
+    period = sampling_freq / artefact_freq * (1.0 + detune)
+    phases, gains, offsets = _artefact_params(n_chans, period)
+    n = np.arange(n_samples, dtype=np.float64)
+    out = np.empty((n_chans, n_samples), dtype=dtype)
+    for c in range(n_chans):
+        theta = (2.0 * np.pi / period) * (n + offsets[c])
+        art = np.zeros(n_samples)
+        for k in range(1, N_HARMONICS + 1):
+            art += np.sin(k * theta + phases[k - 1]) / k
+        noise = np.random.default_rng(1000 + seed + c).standard_normal(n_samples)
+        out[c] = noise + gains[c] * art
+    return out
+
+
+def synth_recording_device(n_chans: int, n_samples: int, sampling_freq: float, artefact_freq: float,
+                           seed: int = 0, detune: float = 3e-5, dtype=None, device="cuda",
+                           chunk: int = 1 << 22):
+    """Same distribution generated directly in HBM (torch RNG for the background; the artefact
+    term is identical to :func:`synth_recording`).  Built in time chunks to bound temporaries."""
+    import torch
+
+    dtype = dtype or torch.float64
+    period = sampling_freq / artefact_freq * (1.0 + detune)
+    phases, gains, offsets = _artefact_params(n_chans, period)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1000 + seed)
+    out = torch.empty((n_chans, n_samples), dtype=dtype, device=device)
+    d_ph = torch.from_numpy(phases).to(device)
+    d_gain = torch.from_numpy(gains).to(device)[:, None]
+    d_off = torch.from_numpy(offsets).to(device)[:, None]
+    w0 = 2.0 * np.pi / period
+    for lo in range(0, n_samples, chunk):
+        hi = min(lo + chunk, n_samples)
+        n = torch.arange(lo, hi, dtype=torch.float64, device=device)[None, :]
+        theta = w0 * (n + d_off)
+        art = torch.zeros((n_chans, hi - lo), dtype=torch.float64, device=device)
+        for k in range(1, N_HARMONICS + 1):
+            art += torch.sin(k * theta + d_ph[k - 1]) / k
+        noise = torch.randn((n_chans, hi - lo), dtype=torch.float64, device=device, generator=gen)
+        out[:, lo:hi] = (noise + d_gain * art).to(dtype)
+        del art, noise, theta
+    return out

@@ -1,0 +1,384 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures written from the unmodified reference.  Run with ``pytest -m gpu`` on an MI355X.
+
+Tolerances (float64; BASELINE.json north_star: 1e-6 relative):
+  filter_data   max|y - y_oracle| <= 1e-10 * max|y_oracle|  (asserted 4 orders tighter than 1e-6)
+  fit errors    rtol 1e-9
+  period        |T - T_ref| <= 1e-9 * T_ref and identical filter taps
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import parrm_oracle as orc  # noqa: E402
+from pyparrm_amd import PARRM, _hip, get_example_data_paths  # noqa: E402
+from pyparrm_amd.synth import synth_recording  # noqa: E402
+
+FILTER_RTOL = 1e-10
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _hip.require_gpu()  # fails loudly (no skip) when the extension or the GPU is missing
+    torch.cuda.set_device(0)
+
+
+def _variants(plan):
+    out = [_hip.KERNEL_GATHER]
+    if plan.info.stride > 0:
+        out.append(_hip.KERNEL_STRIDE)
+    return out
+
+
+def _run_filter(plan, x, kernel, out_dtype=None):
+    plan.set_kernel(kernel)
+    try:
+        return plan.apply(torch.from_numpy(x).cuda(), out_dtype=out_dtype).cpu().numpy()
+    finally:
+        plan.set_kernel(_hip.KERNEL_AUTO)
+
+
+def _assert_filter_close(y, ref, rtol=FILTER_RTOL, mask=None):
+    scale = max(float(np.abs(ref).max()), 1e-300)
+    diff = np.abs(y - ref)
+    if mask is not None:
+        diff = diff[:, mask]
+    assert diff.size == 0 or diff.max() <= rtol * scale, f"max diff {diff.max():.3e} vs scale {scale:.3e}"
+
+
+# ---------------------------------------------------------------------------- filter_data
+def test_filter_matlab_known_answer(golden):
+    """examples/plot_use_parrm.py:77-80,135-141,235-240 -- the reference's own numerical pin."""
+    x = np.load(get_example_data_paths("example_data"))
+    matlab = np.load(get_example_data_paths("matlab_filtered"))
+    filt = golden("filter_data.npz")["example_filter"]
+    plan = _hip.FilterPlan(filt)
+    for k in _variants(plan):
+        y = _run_filter(plan, x, k)
+        assert np.allclose(y, matlab)  # the reference's check
+        _assert_filter_close(y, matlab)
+        _assert_filter_close(y, golden("filter_data.npz")["example_filtered"])
+
+
+@pytest.mark.parametrize("tag", ["both", "past", "future"])
+def test_filter_golden_synth(golden, tag):
+    g = golden("filter_data.npz")
+    x, filt, ref = g["synth_x"], g[f"synth_{tag}_filter"], g[f"synth_{tag}_y"]
+    plan = _hip.FilterPlan(filt)
+    ok = orc.valid_tap_counts(filt, x.shape[1]) > 0
+    direct = orc.filter_data_direct(x, filt)
+    for k in _variants(plan):
+        y = _run_filter(plan, x, k)
+        _assert_filter_close(y, ref, mask=ok)  # vs the reference (FFT noise where no tap is valid)
+        _assert_filter_close(y, direct)        # vs the closed form, everywhere
+        assert np.all(y[:, ~ok] == 0)
+        # data shorter than the filter (tests/test_parrm.py:58-60)
+        xs, ys = g[f"short_{tag}_x"], g[f"short_{tag}_y"]
+        oks = orc.valid_tap_counts(filt, xs.shape[1]) > 0
+        y_s = _run_filter(plan, xs, k)
+        _assert_filter_close(y_s, ys, mask=oks)
+        assert np.all(y_s[:, ~oks] == 0)
+
+
+def test_filter_f32_promotes_to_f64(golden):
+    g = golden("filter_data.npz")
+    filt = g["synth_both_filter"]
+    x32 = g["synth_x"].astype(np.float32)
+    plan = _hip.FilterPlan(filt)
+    ref = g["synth_f32_y"]  # the reference runs the float32 FFT in single precision: ~1e-6 noise
+    direct = orc.filter_data_direct(x32, filt)  # float64 accumulation of the float32 samples
+    for k in _variants(plan):
+        y = _run_filter(plan, x32, k)
+        assert y.dtype == np.float64
+        _assert_filter_close(y, ref, rtol=1e-5)
+        _assert_filter_close(y, direct)
+        y32 = _run_filter(plan, x32, k, out_dtype=torch.float32)
+        assert y32.dtype == np.float32
+        _assert_filter_close(y32.astype(np.float64), direct, rtol=5e-7)
+
+
+FILTER_CASES = [
+    # (period, hw, omit, direction, phw)
+    (169.23584615384616, 2372, 0, "both", None),
+    (169.23584615384616, 2372, 7, "past", None),
+    (7.742402205597892, 2477, 0, "both", None),
+    (7.742402205597892, 300, 10, "future", 0.5),
+    (1.3311148014466094, 2000, 20, "both", 0.01),
+    (50.0, 120, 0, "both", 50.0),       # every offset is a tap (box filter)
+    (2.023966953751087, 49, 0, "both", None),  # two taps only
+    (33.3, 7000, 0, "both", None),      # long half-width (large LDS ring)
+    (169.2, 9000, 0, "both", None),     # half-width beyond the LDS ring: gather kernel only
+]
+
+
+@pytest.mark.parametrize("case", FILTER_CASES)
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (3, 50), (1, 169), (5, 1000), (2, 20011), (3, 70001)])
+def test_filter_shapes_and_taps(case, shape):
+    period, hw, omit, direction, phw = case
+    filt = orc.generate_filter(period, hw, omit, direction, phw)
+    rng = np.random.default_rng(hash((shape, hw)) % (2**32))
+    x = rng.standard_normal(shape) * 3.0 + 10.0  # DC offset stresses cancellation
+    ref = orc.filter_data_direct(x, filt)
+    plan = _hip.FilterPlan(filt)
+    for k in _variants(plan):
+        y = _run_filter(plan, x, k)
+        assert y.shape == x.shape
+        _assert_filter_close(y, ref, rtol=1e-10)
+
+
+def test_filter_strided_rows_and_auto_kernel():
+    filt = orc.generate_filter(169.23584615384616, 2372, 0, "both", None)
+    rng = np.random.default_rng(5)
+    big = rng.standard_normal((6, 90000))
+    d_big = torch.from_numpy(big).cuda()
+    view = d_big[:, 1000:81001]  # row stride 90000, 80001 samples, 8-byte-aligned only
+    plan = _hip.FilterPlan(filt)
+    assert plan.info.kernel == _hip.KERNEL_STRIDE
+    y = plan.apply(view).cpu().numpy()
+    _assert_filter_close(y, orc.filter_data_direct(big[:, 1000:81001], filt))
+    out = torch.zeros((6, 100000), dtype=torch.float64, device="cuda")
+    plan.apply(view, out=out[:, 5:80006])
+    assert torch.equal(out[:, 5:80006].cpu(), torch.from_numpy(y))
+    assert float(out[:, :5].abs().sum()) == 0 and float(out[:, 80006:].abs().sum()) == 0
+
+
+def test_filter_kernels_agree_bitwise_free_and_shard_invariant():
+    """Channel shards are independent: filtering rows separately is bit-identical."""
+    filt = orc.generate_filter(169.23584615384616, 2372, 0, "both", None)
+    x = synth_recording(8, 150000, 22000, 130, seed=2)
+    plan = _hip.FilterPlan(filt)
+    d = torch.from_numpy(x).cuda()
+    whole = plan.apply(d)
+    parts = torch.cat([plan.apply(d[lo:lo + 2]) for lo in range(0, 8, 2)])
+    assert torch.equal(whole, parts)
+    again = plan.apply(d)
+    assert torch.equal(whole, again)  # deterministic run to run
+
+
+def test_filter_window_and_host_streaming():
+    filt = orc.generate_filter(169.23584615384616, 2372, 3, "both", None)
+    hw = 2372
+    x = synth_recording(3, 60000, 22000, 130, seed=4)
+    plan = _hip.FilterPlan(filt)
+    whole = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+    n_total = x.shape[1]
+    pieces = []
+    for o0 in range(0, n_total, 17000):
+        olen = min(17000, n_total - o0)
+        b0, b1 = max(o0 - hw, 0), min(o0 + olen + hw, n_total)
+        xb = torch.from_numpy(np.ascontiguousarray(x[:, b0:b1])).cuda()
+        pieces.append(plan.apply_window(xb, b0, o0, olen, n_total).cpu().numpy())
+    chunked = np.concatenate(pieces, axis=1)
+    _assert_filter_close(chunked, whole, rtol=1e-12)
+    streamed = plan.apply_host(x, chunk_samples=13001)
+    _assert_filter_close(streamed, whole, rtol=1e-12)
+    streamed32 = plan.apply_host(x.astype(np.float32), out_dtype=np.float32, chunk_samples=20000)
+    _assert_filter_close(streamed32.astype(np.float64), whole, rtol=1e-5)
+
+
+def test_filter_nonfinite_outputs_are_zeroed():
+    filt = orc.generate_filter(20.0, 100, 0, "both", None)
+    x = np.random.default_rng(1).standard_normal((2, 3000))
+    x[0, 1500] = np.inf
+    plan = _hip.FilterPlan(filt)
+    for k in _variants(plan):
+        y = _run_filter(plan, x, k)
+        assert np.all(np.isfinite(y))
+        np.testing.assert_allclose(y[1], orc.filter_data_direct(x[1:], filt)[0], rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------- find_period pieces
+def test_absdiff_mean_and_gather(golden):
+    g = golden("standardise.npz")
+    x = g["x"]
+    d = torch.from_numpy(x).cuda()
+    scale = _hip.absdiff_mean(d)
+    np.testing.assert_allclose(scale.cpu().numpy(), np.abs(np.diff(x, axis=1)).mean(axis=1), rtol=1e-13)
+    idx = np.arange(x.shape[1] - 1)
+    y = _hip.gather_standardise(d, torch.from_numpy(idx).cuda(), scale, float(g["outlier_boundary"]))
+    np.testing.assert_allclose(y.cpu().numpy().T, g["std"], rtol=1e-13, atol=1e-15)
+    # larger, ragged length, strided rows
+    rng = np.random.default_rng(8)
+    big = rng.standard_normal((5, 200003)) * np.array([[1], [3], [0.1], [20], [7]])
+    dv = torch.from_numpy(big).cuda()[:, 3:]
+    scale = _hip.absdiff_mean(dv).cpu().numpy()
+    np.testing.assert_allclose(scale, np.abs(np.diff(big[:, 3:], axis=1)).mean(axis=1), rtol=1e-13)
+    b32 = big.astype(np.float32)
+    s32 = _hip.absdiff_mean(torch.from_numpy(b32).cuda()).cpu().numpy()
+    ref32 = np.abs(np.diff(b32, axis=1)).astype(np.float64).mean(axis=1)
+    np.testing.assert_allclose(s32, ref32, rtol=1e-12)
+
+
+def _ecog_stage(indices):
+    ecog = np.load(get_example_data_paths("ecog_lfp_data"))
+    d = torch.from_numpy(ecog).cuda()
+    scale = _hip.absdiff_mean(d)
+    d_idx = torch.from_numpy(np.ascontiguousarray(indices)).cuda()
+    return _hip.gather_standardise(d, d_idx, scale, 3.0), d_idx
+
+
+def test_fit_errors_golden(golden):
+    g = golden("fit_errors_ecog.npz")
+    y, d_idx = _ecog_stage(g["idx1"])
+    np.testing.assert_allclose(y.cpu().numpy().T[:, :64], g["std_cols1"], rtol=1e-13, atol=1e-15)
+    e1 = _hip.fit_errors(y, d_idx, g["per1"], 5, 1.0)
+    np.testing.assert_allclose(e1, g["err1"], rtol=1e-9)
+    e10 = _hip.fit_errors(y, d_idx, np.array([7.7424]), 10, 1.0)
+    np.testing.assert_allclose(e10[0], float(g["err_arr"]), rtol=1e-9)
+    y3, d_idx3 = _ecog_stage(g["idx3"])
+    e3 = _hip.fit_errors(y3, d_idx3, g["per3"], 20, 1.0)
+    np.testing.assert_allclose(e3, g["err3"], rtol=1e-9)
+    e30 = _hip.fit_errors(y3, d_idx3, g["per3"], 20, 0.0)
+    np.testing.assert_allclose(e30, g["err3_l0"], rtol=1e-9)
+    # one candidate at a time (the Nelder-Mead regime: sample-split + reduce) == batched
+    single = np.array([_hip.fit_errors(y3, d_idx3, g["per3"][i:i + 1], 20, 1.0)[0] for i in range(3)])
+    np.testing.assert_allclose(single, e3[:3], rtol=1e-12)
+
+
+def test_fit_errors_many_channels_vs_oracle():
+    x = synth_recording(300, 12000, 22000, 130, seed=3)  # > 256 channels: two column blocks
+    std = orc.standardise_data(x, 3.0)
+    idx = np.arange(3000, 8001)
+    d = torch.from_numpy(x).cuda()
+    scale = _hip.absdiff_mean(d)
+    d_idx = torch.from_numpy(idx).cuda()
+    y = _hip.gather_standardise(d, d_idx, scale, 3.0)
+    periods = 169.2359 * (1 + np.linspace(-1e-3, 1e-3, 5))
+    for bw, lam in ((5, 1.0), (10, 1.0), (20, 0.0)):
+        ref = orc.grid_errors(periods, std, idx, bw, lam)
+        out = _hip.fit_errors(y, d_idx, periods, bw, lam)
+        np.testing.assert_allclose(out, ref, rtol=1e-9)
+
+
+def test_fit_errors_singular_is_inf():
+    # all-zero design column pair: sin(k*a) == 0 exactly is not reachable, but a zero data
+    # matrix with n < K makes W'W exactly rank deficient -> +inf like LinAlgError (:627-628)
+    y = torch.zeros((3, 2), dtype=torch.float64, device="cuda")
+    d_idx = torch.arange(3, dtype=torch.int64, device="cuda")
+    out = _hip.fit_errors(y, d_idx, np.array([2.0, 3.0]), 5, 1.0)
+    assert out.shape == (2,)
+    assert np.all(~np.isfinite(out) | (out >= 0))
+
+
+# ---------------------------------------------------------------------------- find_period
+def _same_taps(p_gpu, p_ref, n_samples, **kw):
+    hw = orc.default_filter_half_width(n_samples, p_ref, 0, p_ref / 50)
+    a = orc.generate_filter(p_gpu, hw, 0, "both", p_gpu / 50)
+    b = orc.generate_filter(p_ref, hw, 0, "both", p_ref / 50)
+    return np.array_equal(a != 0, b != 0)
+
+
+def test_period_example_data(golden):
+    ref = float(golden("periods.npz")["example_data"])
+    x = np.load(get_example_data_paths("example_data"))
+    p = PARRM(x, 200, 150, verbose=False)
+    p.find_period()
+    assert isinstance(p.period, np.float64)
+    assert abs(p.period - ref) <= 1e-9 * ref, (p.period, ref)
+    # the full reference flow reproduces the MATLAB output (plot_use_parrm.py:135-141,239)
+    p.create_filter(filter_half_width=2000, omit_n_samples=20, filter_direction="both",
+                    period_half_width=0.01)
+    assert np.array_equal(p.filter, golden("filter_data.npz")["example_filter"])
+    y = p.filter_data()
+    assert np.allclose(y, np.load(get_example_data_paths("matlab_filtered")))
+
+
+def test_period_ecog_seed44(golden):
+    ref = float(golden("periods.npz")["ecog_lfp_data_seed44"])
+    x = np.load(get_example_data_paths("ecog_lfp_data"))
+    p = PARRM(x, 1000, 130, verbose=False)
+    p.find_period(random_seed=44)
+    assert abs(p.period - ref) <= 1e-9 * ref, (p.period, ref)
+    assert _same_taps(p.period, ref, x.shape[1])
+
+
+def test_period_synth_and_options(golden):
+    g = golden("periods.npz")
+    p = PARRM(g["synth_4x30000"], 22000, 130, verbose=False)
+    p.find_period(random_seed=3)
+    ref = float(g["synth_4x30000_seed3"])
+    assert abs(p.period - ref) <= 1e-9 * ref, (p.period, ref)
+    assert _same_taps(p.period, ref, 30000)
+    p2 = PARRM(g["synth_3x6000"], 1000, 130, verbose=False)
+    p2.find_period(search_samples=np.arange(0, 3000.0), assumed_periods=(7.6, 7.7), random_seed=1)
+    ref2 = float(g["synth_3x6000_half_two_estimates"])
+    assert abs(p2.period - ref2) <= 1e-9 * ref2, (p2.period, ref2)
+
+
+def test_period_nonfinite_data_raises():
+    x = np.random.default_rng(0).standard_normal((1, 3000))
+    x[0, 100] = np.nan
+    p = PARRM(x, 1000, 130, verbose=False)
+    with pytest.raises(ValueError, match="The period cannot be estimated from the data."):
+        p.find_period()
+
+
+# ---------------------------------------------------------------------------- facade smoke (reference tests/test_parrm.py:17-68)
+@pytest.mark.parametrize("n_chans", [1, 2])
+@pytest.mark.parametrize("n_samples", [100, 300, 25000])
+@pytest.mark.parametrize("half", [False, True])
+def test_facade_reference_smoke(n_chans, n_samples, half):
+    rng = np.random.default_rng(44)
+    data = rng.standard_normal((n_chans, n_samples))
+    p = PARRM(data=data, sampling_freq=20, artefact_freq=10, verbose=False)
+    search = np.arange(0, n_samples * 0.5) if half else None
+    p.find_period(search_samples=search, assumed_periods=20 / 10, random_seed=44, n_jobs=2)
+    for direction in ["future", "past", "both"]:
+        p.create_filter(filter_direction=direction)
+    y = p.filter_data()
+    assert y.shape == data.shape and isinstance(y, np.ndarray) and y.dtype == np.float64
+    assert y is p.filtered_data
+    _assert_filter_close(y, orc.filter_data_direct(data, p.filter))
+    other = rng.standard_normal((1, 50))
+    assert p.filter_data(other).shape == other.shape
+    assert repr(p) == (
+        f"PARRM object | Data: ({n_chans} channels x {n_samples} times) | Period: {p.period :.4f}"
+    )
+
+
+def test_facade_device_tensor_roundtrip():
+    x = synth_recording(4, 50000, 22000, 130, seed=6)
+    d = torch.from_numpy(x).cuda()
+    p = PARRM(d, 22000, 130, verbose=False)
+    p.find_period(random_seed=2)
+    p.create_filter()
+    y = p.filter_data()
+    assert isinstance(y, torch.Tensor) and y.is_cuda and y.dtype == torch.float64
+    _assert_filter_close(y.cpu().numpy(), orc.filter_data_direct(x, p.filter))
+
+
+# ---------------------------------------------------------------------------- BASELINE-size properties
+def test_config2_properties_64ch_1M():
+    """BASELINE config 2 (64 ch x 1 Msample f64): size-independent properties + sampled oracle."""
+    n_chans, n_samples = 64, 1_000_000
+    filt = orc.generate_filter(169.23584615384616, 2372, 0, "both", None)
+    plan = _hip.FilterPlan(filt)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn((n_chans, n_samples), dtype=torch.float64, device="cuda", generator=g)
+    b = torch.randn((n_chans, n_samples), dtype=torch.float64, device="cuda", generator=g)
+    ya, yb = plan.apply(a), plan.apply(b)
+    # linearity
+    yc = plan.apply(2.5 * a - 0.75 * b)
+    assert float((yc - (2.5 * ya - 0.75 * yb)).abs().max()) < 1e-11
+    # a constant is its own phase-neighbourhood mean -> exactly removable
+    ones = torch.full((2, n_samples), 7.25, dtype=torch.float64, device="cuda")
+    assert float(plan.apply(ones).abs().max()) < 1e-12
+    # a signal with an exactly periodic integer period that the taps hit is annihilated inside
+    per = 13
+    f13 = orc.generate_filter(float(per), 650, 0, "both", 0.25)
+    ramp = (torch.arange(n_samples, device="cuda") % per).to(torch.float64)[None, :].repeat(2, 1)
+    y13 = _hip.FilterPlan(f13).apply(ramp)
+    assert float(y13.abs().max()) < 1e-12
+    # sampled closed-form check of three channels
+    rows = [0, 31, 63]
+    ref = orc.filter_data_direct(a[rows].cpu().numpy(), filt)
+    _assert_filter_close(ya[rows].cpu().numpy(), ref)
+    # gather kernel == stride kernel to rounding on a slice
+    plan.set_kernel(_hip.KERNEL_GATHER)
+    yg = plan.apply(a[:2])
+    plan.set_kernel(_hip.KERNEL_AUTO)
+    assert float((yg - ya[:2]).abs().max()) < 1e-11
