@@ -59,6 +59,10 @@ class HipLibraryError(RuntimeError):
 _lib = None
 _lock = threading.Lock()
 
+# bench.py sets this to a list: every filter launch then appends a (start, stop) pair of HIP
+# events recorded on the launch's own stream, so the kernel's duration can be read after a sync
+FILTER_LAUNCH_EVENTS = None
+
 
 def library_path() -> str:
     return _LIB_PATH
@@ -208,6 +212,10 @@ class FilterPlan:
         ldx = x.stride(0) if n_chans > 1 else max(x.stride(0), n_samples)
         ldy = out.stride(0) if n_chans > 1 else max(out.stride(0), n_samples)
         with torch.cuda.device(x.device):
+            events = None
+            if FILTER_LAUNCH_EVENTS is not None:
+                events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                events[0].record()  # torch's current stream == the stream passed to the launch
             check(
                 lib().parrm_filter_apply(
                     self._h, x.data_ptr(), _dtype_code(x), out.data_ptr(), _dtype_code(out),
@@ -215,6 +223,9 @@ class FilterPlan:
                 ),
                 "parrm_filter_apply",
             )
+            if events is not None:
+                events[1].record()
+                FILTER_LAUNCH_EVENTS.append(events)
         return out
 
     def apply_window(self, x, buf_first: int, out_first: int, out_len: int, n_total: int, out=None):

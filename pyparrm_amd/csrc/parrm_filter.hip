@@ -40,8 +40,9 @@ struct FilterArgs {
     int64_t ldx, ldy;
     const int32_t *runs;    // [n_runs][2] inclusive tap runs (w_lo, w_hi), ascending
     const int32_t *tapcum;  // [2*hw+2]: tapcum[j] = #taps with w < j - hw
-    const int32_t *delta;   // [n_plus + n_minus] offsets u of d_q: first the +1 taps, then the -1
-    int32_t n_runs, n_plus, n_minus;
+    const int32_t *delta;   // [n_delta_pad] offsets u of d_q = tap(.+q) - tap(.)
+    const double *delta_w;  // [n_delta_pad] +1 / -1, and 0 for the padding entries
+    int32_t n_runs, n_delta_pad;
     int32_t hw, n_taps;
     int32_t q, ring_mask, rows_per_fill;
     int64_t stretch_len, n_stretch;
@@ -99,8 +100,10 @@ __device__ inline TI load_padded(const FilterArgs &a, const TI *row, int64_t g) 
 }
 
 // One workgroup = one (channel, stretch).  Threads r < q own residue r of the stretch; rows of q
-// outputs are produced in lockstep, `rows_per_fill` rows per barrier.
-template <typename TI, typename TO>
+// outputs are produced in lockstep, `rows_per_fill` rows per barrier.  D = padded number of delta
+// taps; their byte offsets and weights live in VGPRs for the whole kernel (a scalar-memory load per
+// tap inside the row loop serialises on lgkmcnt and was measured 15x slower).
+template <typename TI, typename TO, int D>
 __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     TI *ring = reinterpret_cast<TI *>(lds_raw);
@@ -111,6 +114,17 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
     const int mask = a.ring_mask;
     const int G = a.rows_per_fill;
     const int hw = a.hw;
+    constexpr int kEl = static_cast<int>(sizeof(TI));
+    const int maskb = mask * kEl;  // byte mask for element-aligned addresses (mask = 2^k - 1)
+
+    // the delta table is staged behind the ring so that each lane reads it into registers with
+    // LDS loads (VGPR results) instead of scalar loads
+    int32_t *tab_off = reinterpret_cast<int32_t *>(lds_raw + static_cast<size_t>(mask + 1) * kEl);
+    double *tab_w = reinterpret_cast<double *>(tab_off + 128);
+    for (int i = tid; i < D; i += nthr) {
+        tab_off[i] = a.delta[i] * kEl;
+        tab_w[i] = a.delta_w[i];
+    }
 
     const int64_t blk = blockIdx.x;
     const int64_t c = blk / a.n_stretch;
@@ -125,6 +139,14 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
     int fill = (G + 1) * q + hw;  // exclusive front, relative to s0
     for (int rel = -hw + tid; rel < fill; rel += nthr) ring[rel & mask] = load_padded(a, row, s0 + rel);
     __syncthreads();
+
+    int offb[D];
+    double wv[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        offb[i] = tab_off[i];
+        wv[i] = tab_w[i];
+    }
 
     const bool active = tid < q;
     double S = 0.0;
@@ -142,10 +164,6 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
         S = s_a + s_b;
     }
 
-    const int n_plus = a.n_plus, n_minus = a.n_minus;
-    const int32_t *dplus = a.delta;
-    const int32_t *dminus = a.delta + n_plus;
-
     for (int m = 0; m * q < len; m += G) {
         // 1. issue the next fill's global loads; they land while the rows below are computed
         const bool more = (m + G) * q < len;  // wave-uniform
@@ -159,21 +177,22 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
         if (active) {
             for (int j = 0; j < G; ++j) {
                 const int rel = (m + j) * q + tid;
+                if ((m + j) * q >= len) break;
                 if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
-                double p0 = 0.0, p1 = 0.0, m0 = 0.0, m1 = 0.0;
-                int i = 0;
-                for (; i + 1 < n_plus; i += 2) {
-                    p0 += static_cast<double>(ring[(rel - dplus[i]) & mask]);
-                    p1 += static_cast<double>(ring[(rel - dplus[i + 1]) & mask]);
+                const int relb = rel * kEl;
+                double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; i += 4) {
+                    const TI v0 = *reinterpret_cast<const TI *>(lds_raw + ((relb - offb[i]) & maskb));
+                    const TI v1 = *reinterpret_cast<const TI *>(lds_raw + ((relb - offb[i + 1]) & maskb));
+                    const TI v2 = *reinterpret_cast<const TI *>(lds_raw + ((relb - offb[i + 2]) & maskb));
+                    const TI v3 = *reinterpret_cast<const TI *>(lds_raw + ((relb - offb[i + 3]) & maskb));
+                    acc0 = fma(wv[i], static_cast<double>(v0), acc0);
+                    acc1 = fma(wv[i + 1], static_cast<double>(v1), acc1);
+                    acc2 = fma(wv[i + 2], static_cast<double>(v2), acc2);
+                    acc3 = fma(wv[i + 3], static_cast<double>(v3), acc3);
                 }
-                if (i < n_plus) p0 += static_cast<double>(ring[(rel - dplus[i]) & mask]);
-                i = 0;
-                for (; i + 1 < n_minus; i += 2) {
-                    m0 += static_cast<double>(ring[(rel - dminus[i]) & mask]);
-                    m1 += static_cast<double>(ring[(rel - dminus[i + 1]) & mask]);
-                }
-                if (i < n_minus) m0 += static_cast<double>(ring[(rel - dminus[i]) & mask]);
-                S += (p0 + p1) - (m0 + m1);
+                S += (acc0 + acc1) + (acc2 + acc3);
             }
         }
         // 3. publish the prefetched samples (their slots alias data older than row m - see DESIGN.md)
@@ -194,10 +213,11 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
 struct parrm_filter_plan {
     int device = 0;
     int64_t hw = 0, n_taps = 0, n_runs = 0;
-    int64_t q = 0, n_plus = 0, n_minus = 0;
+    int64_t q = 0, n_delta = 0, n_delta_pad = 0;
     int ring_log2_f64 = 0, rows_per_fill = 0, block_threads = 0;
     int forced_kernel = PARRM_KERNEL_AUTO;
-    int32_t *d_tables = nullptr;  // runs | tapcum | delta, one allocation
+    int32_t *d_tables = nullptr;  // runs | tapcum | delta offsets, one allocation
+    double *d_weights = nullptr;  // delta weights
     int64_t off_tapcum = 0, off_delta = 0;
 };
 
@@ -209,10 +229,17 @@ int next_pow2_log2(int64_t v) {
     return l;
 }
 
+constexpr int kDeltaSizes[] = {8, 16, 24, 32, 48, 64, 96, 128};
+
+int padded_delta(int64_t n) {  // smallest compiled unroll >= n, 0 if none
+    for (int d : kDeltaSizes)
+        if (n <= d) return d;
+    return 0;
+}
+
 // Choose the recurrence stride: minimise (LDS reads per output row) / (lane utilisation).
 void choose_stride(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p,
-                   std::vector<int32_t> *delta) {
-    const int64_t L = 2 * hw + 1;
+                   std::vector<int32_t> *delta, std::vector<double> *weights) {
     double best_cost = 1e300;
     int64_t best_q = 0;
     auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
@@ -220,27 +247,33 @@ void choose_stride(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan
         if (2 * hw + 3 * q > (int64_t{1} << kMaxRingLog2F64)) break;
         int64_t nd = 0;
         for (int64_t u = -hw - q; u <= hw; ++u) nd += tap_at(u + q) != tap_at(u);
+        const int pad = padded_delta(nd);
+        if (pad == 0) continue;
         const int64_t block = (q + 63) / 64 * 64;
-        const double cost = static_cast<double>(nd + 6) * static_cast<double>(block) / static_cast<double>(q);
+        const double cost = static_cast<double>(pad + 6) * static_cast<double>(block) / static_cast<double>(q);
         if (cost < best_cost - 1e-12 || (std::fabs(cost - best_cost) <= 1e-12 && q > best_q)) {
             best_cost = cost;
             best_q = q;
         }
     }
-    (void)L;
     p->q = best_q;
-    if (best_q == 0) return;  // half-width too large for the LDS ring -> gather kernel only
+    if (best_q == 0) return;  // half-width too large for the LDS ring (or no sparse d_q) -> gather kernel
     const int64_t q = best_q;
-    std::vector<int32_t> plus, minus;
     for (int64_t u = -hw - q; u <= hw; ++u) {
         const int d = tap_at(u + q) - tap_at(u);
-        if (d > 0) plus.push_back(static_cast<int32_t>(u));
-        if (d < 0) minus.push_back(static_cast<int32_t>(u));
+        if (d != 0) {
+            delta->push_back(static_cast<int32_t>(u));
+            weights->push_back(static_cast<double>(d));
+        }
     }
-    p->n_plus = static_cast<int64_t>(plus.size());
-    p->n_minus = static_cast<int64_t>(minus.size());
-    delta->assign(plus.begin(), plus.end());
-    delta->insert(delta->end(), minus.begin(), minus.end());
+    p->n_delta = static_cast<int64_t>(delta->size());
+    p->n_delta_pad = padded_delta(p->n_delta);
+    // padding entries re-read a real delta tap with weight 0: they add exactly 0 unless that sample
+    // is non-finite, in which case the real tap poisons the sum anyway
+    while (static_cast<int64_t>(delta->size()) < p->n_delta_pad) {
+        delta->push_back((*delta)[0]);
+        weights->push_back(0.0);
+    }
     p->block_threads = static_cast<int>((q + 63) / 64 * 64);
     p->ring_log2_f64 = next_pow2_log2(2 * hw + 3 * q);
     int g = kMaxRowsPerFill;
@@ -284,8 +317,20 @@ int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t str
     a.n_stretch = (a.out_len + a.stretch_len - 1) / a.stretch_len;
     const int64_t blocks = a.n_chans * a.n_stretch;
     PARRM_REQUIRE(blocks <= 0x7fffffffLL, "filter: too many workgroups for one launch");
-    const size_t lds = (size_t{1} << ring_log2) * sizeof(TI);
-    auto kern = filter_stride_kernel<TI, TO>;
+    const size_t lds = (size_t{1} << ring_log2) * sizeof(TI) + 128 * sizeof(int32_t) + 128 * sizeof(double);
+    a.n_delta_pad = static_cast<int32_t>(p->n_delta_pad);
+    void (*kern)(FilterArgs) = nullptr;
+    switch (p->n_delta_pad) {
+        case 8: kern = filter_stride_kernel<TI, TO, 8>; break;
+        case 16: kern = filter_stride_kernel<TI, TO, 16>; break;
+        case 24: kern = filter_stride_kernel<TI, TO, 24>; break;
+        case 32: kern = filter_stride_kernel<TI, TO, 32>; break;
+        case 48: kern = filter_stride_kernel<TI, TO, 48>; break;
+        case 64: kern = filter_stride_kernel<TI, TO, 64>; break;
+        case 96: kern = filter_stride_kernel<TI, TO, 96>; break;
+        case 128: kern = filter_stride_kernel<TI, TO, 128>; break;
+        default: parrm::set_error("filter: no stride kernel for %lld delta taps", (long long)p->n_delta_pad); return PARRM_ERR_INVALID;
+    }
     PARRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(p->block_threads), lds, stream, a);
@@ -339,7 +384,9 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     std::vector<int32_t> tapcum(2 * hw + 2, 0);
     for (int64_t j = 0; j < filter_len; ++j) tapcum[j + 1] = tapcum[j] + tap[j];
     std::vector<int32_t> delta;
-    choose_stride(tap, hw, p, &delta);
+    std::vector<double> weights;
+    choose_stride(tap, hw, p, &delta, &weights);
+    weights.push_back(0.0);
 
     std::vector<int32_t> tables(runs);
     p->off_tapcum = static_cast<int64_t>(tables.size());
@@ -351,7 +398,11 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     if (e == hipSuccess) e = hipMalloc(&p->d_tables, tables.size() * sizeof(int32_t));
     if (e == hipSuccess)
         e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->d_weights, weights.size() * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMemcpy(p->d_weights, weights.data(), weights.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        if (p->d_weights) (void)hipFree(p->d_weights);
         if (p->d_tables) (void)hipFree(p->d_tables);
         delete p;
         return parrm::hip_fail(e, "filter_plan_create: table upload");
@@ -363,6 +414,7 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
 int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
     if (!plan) return PARRM_OK;
     if (plan->d_tables) (void)hipFree(plan->d_tables);
+    if (plan->d_weights) (void)hipFree(plan->d_weights);
     delete plan;
     return PARRM_OK;
 }
@@ -373,7 +425,7 @@ int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_inf
     info->n_taps = plan->n_taps;
     info->n_runs = plan->n_runs;
     info->stride = plan->q;
-    info->n_delta = plan->n_plus + plan->n_minus;
+    info->n_delta = plan->n_delta;
     info->ring_len = plan->q ? (int64_t{1} << plan->ring_log2_f64) : 0;
     info->rows_per_fill = plan->rows_per_fill;
     info->block_threads = plan->block_threads;
@@ -425,8 +477,7 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
     a.tapcum = plan->d_tables + plan->off_tapcum;
     a.delta = plan->d_tables + plan->off_delta;
     a.n_runs = static_cast<int32_t>(plan->n_runs);
-    a.n_plus = static_cast<int32_t>(plan->n_plus);
-    a.n_minus = static_cast<int32_t>(plan->n_minus);
+    a.delta_w = plan->d_weights;
     a.hw = static_cast<int32_t>(plan->hw);
     a.n_taps = static_cast<int32_t>(plan->n_taps);
     a.inv_taps = 1.0 / static_cast<double>(plan->n_taps);
