@@ -43,7 +43,8 @@ extern "C" {
 /* filter kernel variants (parrm_filter_plan_set_kernel) */
 #define PARRM_KERNEL_AUTO 0
 #define PARRM_KERNEL_GATHER 1 /* one thread per output, taps gathered from global/L2        */
-#define PARRM_KERNEL_STRIDE 2 /* LDS ring + stride-q running-sum recurrence (the fast path)  */
+#define PARRM_KERNEL_STRIDE 2 /* LDS ring + stride-q running-sum recurrence (any tap pattern) */
+#define PARRM_KERNEL_PHASE 3  /* phase-major LDS ring, R rows per thread (comb filters, T>=64) */
 
 int parrm_hip_abi_version(void);
 const char *parrm_hip_last_error(void);
@@ -72,7 +73,13 @@ typedef struct parrm_filter_plan_info {
     int64_t ring_len;    /* LDS ring length in samples                                 */
     int64_t rows_per_fill; /* rows of q samples loaded per fill                        */
     int32_t block_threads;
-    int32_t kernel;      /* variant AUTO resolves to                                   */
+    int32_t kernel;      /* variant AUTO resolves to for a large recording             */
+    int32_t phase_stride;    /* q of the phase-major kernel (0 = unavailable)          */
+    int32_t phase_delta;     /* its padded delta taps (both signs)                     */
+    int32_t phase_guard;     /* mirrored residues per row side                         */
+    int32_t phase_groups;    /* row groups sharing one LDS ring                        */
+    int32_t phase_rows;      /* rows per thread per iteration                          */
+    int32_t phase_row_slots; /* ring length in rows                                    */
 } parrm_filter_plan_info;
 
 int parrm_filter_plan_create(const double *h_filter, int64_t filter_len,

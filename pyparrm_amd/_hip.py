@@ -16,7 +16,7 @@ import numpy as np
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libparrm_hip.so")
 
 F32, F64 = 0, 1
-KERNEL_AUTO, KERNEL_GATHER, KERNEL_STRIDE = 0, 1, 2
+KERNEL_AUTO, KERNEL_GATHER, KERNEL_STRIDE, KERNEL_PHASE = 0, 1, 2, 3
 
 # every symbol include/parrm_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -49,6 +49,12 @@ class PlanInfo(C.Structure):
         ("rows_per_fill", C.c_int64),
         ("block_threads", C.c_int32),
         ("kernel", C.c_int32),
+        ("phase_stride", C.c_int32),
+        ("phase_delta", C.c_int32),
+        ("phase_guard", C.c_int32),
+        ("phase_groups", C.c_int32),
+        ("phase_rows", C.c_int32),
+        ("phase_row_slots", C.c_int32),
     ]
 
 

@@ -22,55 +22,15 @@
 #include <cstring>
 #include <vector>
 
-#include "parrm_common.h"
+#include "parrm_filter_internal.h"
+
+using namespace parrm_filter;
 
 namespace {
 
 constexpr int kMaxRingLog2F64 = 14;  // 16384 * 8 B = 128 KiB of the 160 KiB LDS
 constexpr int kMaxRowsPerFill = 8;
 constexpr int kMaxBlock = 256;
-
-struct FilterArgs {
-    const void *x;
-    void *y;
-    int64_t n_chans;
-    int64_t buf_first, buf_len;  // samples [buf_first, buf_first+buf_len) are addressable in x
-    int64_t out_first, out_len;  // outputs to produce
-    int64_t n_total;             // length of the whole recording (edge logic)
-    int64_t ldx, ldy;
-    const int32_t *runs;    // [n_runs][2] inclusive tap runs (w_lo, w_hi), ascending
-    const int32_t *tapcum;  // [2*hw+2]: tapcum[j] = #taps with w < j - hw
-    const int32_t *delta;   // [n_delta_pad] offsets u of d_q = tap(.+q) - tap(.)
-    const double *delta_w;  // [n_delta_pad] +1 / -1, and 0 for the padding entries
-    int32_t n_runs, n_delta_pad;
-    int32_t hw, n_taps;
-    int32_t q, ring_mask, rows_per_fill;
-    int64_t stretch_len, n_stretch;
-    double inv_taps;
-};
-
-// number of taps whose source sample n-w lies inside [0, n_total)
-__device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
-    const int64_t hw = a.hw;
-    const int64_t w_hi = n < hw ? n : hw;
-    int64_t w_lo = n - a.n_total + 1;
-    if (w_lo < -hw) w_lo = -hw;
-    if (w_hi < w_lo) return 0;
-    return a.tapcum[w_hi + hw + 1] - a.tapcum[w_lo + hw];
-}
-
-template <typename TO>
-__device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
-    double y;
-    if (n >= a.hw && n + a.hw < a.n_total) {
-        y = xc - s * a.inv_taps;
-    } else {
-        const int v = valid_taps(a, n);
-        y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
-    }
-    if (!isfinite(y)) y = 0.0;  // parrm.py:869
-    static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);
-}
 
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) filter_gather_kernel(FilterArgs a) {
@@ -90,13 +50,6 @@ __global__ void __launch_bounds__(256) filter_gather_kernel(FilterArgs a) {
         }
         emit<TO>(a, c, n, static_cast<double>(row[n]), s);
     }
-}
-
-template <typename TI>
-__device__ inline TI load_padded(const FilterArgs &a, const TI *row, int64_t g) {
-    // zero outside the recording; the window contract guarantees everything else is addressable
-    const bool ok = g >= 0 && g < a.n_total && g >= a.buf_first && g < a.buf_first + a.buf_len;
-    return ok ? row[g - a.buf_first] : TI(0);
 }
 
 // One workgroup = one (channel, stretch).  Threads r < q own residue r of the stretch; rows of q
@@ -210,17 +163,6 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
 
 }  // namespace
 
-struct parrm_filter_plan {
-    int device = 0;
-    int64_t hw = 0, n_taps = 0, n_runs = 0;
-    int64_t q = 0, n_delta = 0, n_delta_pad = 0;
-    int ring_log2_f64 = 0, rows_per_fill = 0, block_threads = 0;
-    int forced_kernel = PARRM_KERNEL_AUTO;
-    int32_t *d_tables = nullptr;  // runs | tapcum | delta offsets, one allocation
-    double *d_weights = nullptr;  // delta weights
-    int64_t off_tapcum = 0, off_delta = 0;
-};
-
 namespace {
 
 int next_pow2_log2(int64_t v) {
@@ -282,16 +224,22 @@ void choose_stride(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan
 }
 
 int resolve_kernel(const parrm_filter_plan *p, int64_t n_chans, int64_t out_len) {
-    if (p->forced_kernel == PARRM_KERNEL_GATHER) return PARRM_KERNEL_GATHER;
-    if (p->q == 0) return PARRM_KERNEL_GATHER;
-    if (p->forced_kernel == PARRM_KERNEL_STRIDE) return PARRM_KERNEL_STRIDE;
+    const bool has_phase = p->phase.n_groups > 0, has_stride = p->q != 0;
+    switch (p->forced_kernel) {
+        case PARRM_KERNEL_GATHER: return PARRM_KERNEL_GATHER;
+        case PARRM_KERNEL_STRIDE: return has_stride ? PARRM_KERNEL_STRIDE : PARRM_KERNEL_GATHER;
+        case PARRM_KERNEL_PHASE: return has_phase ? PARRM_KERNEL_PHASE : PARRM_KERNEL_GATHER;
+        default: break;
+    }
     // tiny problems: the per-stretch prologue (2*hw + ... samples) would dominate
     if (n_chans * out_len < (int64_t{1} << 15)) return PARRM_KERNEL_GATHER;
-    return PARRM_KERNEL_STRIDE;
+    if (has_phase) return PARRM_KERNEL_PHASE;
+    return has_stride ? PARRM_KERNEL_STRIDE : PARRM_KERNEL_GATHER;
 }
 
 template <typename TI, typename TO>
 int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
+    if (kernel == PARRM_KERNEL_PHASE) return launch_phase<TI, TO>(p, a, stream);
     if (kernel == PARRM_KERNEL_GATHER) {
         const int block = 256;
         const int64_t gx = (a.out_len + block - 1) / block;
@@ -387,6 +335,9 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     std::vector<double> weights;
     choose_stride(tap, hw, p, &delta, &weights);
     weights.push_back(0.0);
+    std::vector<int32_t> phase_tab;
+    plan_phase(tap, hw, p, &phase_tab);
+    phase_tab.push_back(0);
 
     std::vector<int32_t> tables(runs);
     p->off_tapcum = static_cast<int64_t>(tables.size());
@@ -398,11 +349,15 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     if (e == hipSuccess) e = hipMalloc(&p->d_tables, tables.size() * sizeof(int32_t));
     if (e == hipSuccess)
         e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->d_phase_tab, phase_tab.size() * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMemcpy(p->d_phase_tab, phase_tab.data(), phase_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->d_weights, weights.size() * sizeof(double));
     if (e == hipSuccess)
         e = hipMemcpy(p->d_weights, weights.data(), weights.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (p->d_weights) (void)hipFree(p->d_weights);
+        if (p->d_phase_tab) (void)hipFree(p->d_phase_tab);
         if (p->d_tables) (void)hipFree(p->d_tables);
         delete p;
         return parrm::hip_fail(e, "filter_plan_create: table upload");
@@ -415,6 +370,7 @@ int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
     if (!plan) return PARRM_OK;
     if (plan->d_tables) (void)hipFree(plan->d_tables);
     if (plan->d_weights) (void)hipFree(plan->d_weights);
+    if (plan->d_phase_tab) (void)hipFree(plan->d_phase_tab);
     delete plan;
     return PARRM_OK;
 }
@@ -430,13 +386,21 @@ int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_inf
     info->rows_per_fill = plan->rows_per_fill;
     info->block_threads = plan->block_threads;
     info->kernel = resolve_kernel(plan, int64_t{1} << 20, int64_t{1} << 20);
+    info->phase_stride = plan->phase.n_groups ? plan->phase.q : 0;
+    info->phase_delta = plan->phase.n_groups ? 2 * plan->phase.d_pad : 0;
+    info->phase_guard = plan->phase.guard;
+    info->phase_groups = plan->phase.n_groups;
+    info->phase_rows = plan->phase.rows;
+    info->phase_row_slots = plan->phase.m_slots;
     return PARRM_OK;
 }
 
 int parrm_filter_plan_set_kernel(parrm_filter_plan *plan, int kernel) {
     PARRM_REQUIRE(plan, "filter_plan_set_kernel: NULL plan");
-    PARRM_REQUIRE(kernel == PARRM_KERNEL_AUTO || kernel == PARRM_KERNEL_GATHER || kernel == PARRM_KERNEL_STRIDE,
+    PARRM_REQUIRE(kernel >= PARRM_KERNEL_AUTO && kernel <= PARRM_KERNEL_PHASE,
                   "filter_plan_set_kernel: unknown kernel %d", kernel);
+    PARRM_REQUIRE(kernel != PARRM_KERNEL_PHASE || plan->phase.n_groups != 0,
+                  "filter_plan_set_kernel: this filter has no phase-major plan (period too short or taps too spread)");
     PARRM_REQUIRE(kernel != PARRM_KERNEL_STRIDE || plan->q != 0,
                   "filter_plan_set_kernel: half-width %lld does not fit the LDS ring", (long long)plan->hw);
     plan->forced_kernel = kernel;

@@ -1,0 +1,97 @@
+// Internal to the filter_data kernels (parrm_filter.hip, parrm_filter_phase.hip).
+#pragma once
+
+#include <vector>
+
+#include "parrm_common.h"
+
+namespace parrm_filter {
+
+struct FilterArgs {
+    const void *x;
+    void *y;
+    int64_t n_chans;
+    int64_t buf_first, buf_len;  // samples [buf_first, buf_first+buf_len) are addressable in x
+    int64_t out_first, out_len;  // outputs to produce
+    int64_t n_total;             // length of the whole recording (edge logic)
+    int64_t ldx, ldy;
+    const int32_t *runs;    // [n_runs][2] inclusive tap runs (w_lo, w_hi), ascending
+    const int32_t *tapcum;  // [2*hw+2]: tapcum[j] = #taps with w < j - hw
+    const int32_t *delta;   // [n_delta_pad] offsets u of d_q = tap(.+q) - tap(.)
+    const double *delta_w;  // [n_delta_pad] +1 / -1, and 0 for the padding entries
+    int32_t n_runs, n_delta_pad;
+    int32_t hw, n_taps;
+    int32_t q, ring_mask, rows_per_fill;
+    int64_t stretch_len, n_stretch;
+    double inv_taps;
+};
+
+// number of taps whose source sample n-w lies inside [0, n_total)
+__device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
+    const int64_t hw = a.hw;
+    const int64_t w_hi = n < hw ? n : hw;
+    int64_t w_lo = n - a.n_total + 1;
+    if (w_lo < -hw) w_lo = -hw;
+    if (w_hi < w_lo) return 0;
+    return a.tapcum[w_hi + hw + 1] - a.tapcum[w_lo + hw];
+}
+
+template <typename TO>
+__device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
+    double y;
+    if (n >= a.hw && n + a.hw < a.n_total) {
+        y = xc - s * a.inv_taps;
+    } else {
+        const int v = valid_taps(a, n);
+        y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
+    }
+    if (!isfinite(y)) y = 0.0;  // parrm.py:869
+    static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);
+}
+
+template <typename TI>
+__device__ inline TI load_padded(const FilterArgs &a, const TI *row, int64_t g) {
+    // zero outside the recording; the window contract guarantees everything else is addressable
+    const bool ok = g >= 0 && g < a.n_total && g >= a.buf_first && g < a.buf_first + a.buf_len;
+    return ok ? row[g - a.buf_first] : TI(0);
+}
+
+
+// ---------------------------------------------------------------- phase-major kernel geometry
+struct PhaseGeom {
+    int32_t q, qp;        // stride; q rounded up to whole waves (threads per row group)
+    int32_t guard;        // B: residues mirrored on each side of a row
+    int32_t m_slots;      // M: row slots of the ring
+    int32_t rs;           // elements per residue: M + R - 1 (mirrored head), made odd
+    int32_t n_groups;     // NG row groups sharing the ring
+    int32_t rows;         // R rows per thread per iteration (template parameter of the launch)
+    int32_t a_lo, a_hi;   // tap rows reach from m - a_hi to m - a_lo (+1 look-ahead)
+    int32_t d_pad;        // padded length of the +1 and of the -1 delta lists
+    int32_t n_runs;       // full-tap runs for the per-stretch initialisation
+    int32_t debug;        // ablation bits for profiling builds (PARRM_DEBUG_FLAGS); 0 in production
+    const int32_t *tab;   // [4*d_pad] plus_a', plus_b, minus_a', minus_b ; then [3*n_runs] (a', b_lo, b_hi)
+};
+
+}  // namespace parrm_filter
+
+struct parrm_filter_plan {
+    int device = 0;
+    int64_t hw = 0, n_taps = 0, n_runs = 0;
+    int64_t q = 0, n_delta = 0, n_delta_pad = 0;
+    int ring_log2_f64 = 0, rows_per_fill = 0, block_threads = 0;
+    int forced_kernel = PARRM_KERNEL_AUTO;
+    int32_t *d_tables = nullptr;  // runs | tapcum | delta offsets, one allocation
+    double *d_weights = nullptr;  // delta weights
+    int64_t off_tapcum = 0, off_delta = 0;
+    // phase-major kernel (0 groups = not available for this filter)
+    parrm_filter::PhaseGeom phase{};
+    int32_t *d_phase_tab = nullptr;
+};
+
+
+namespace parrm_filter {
+// parrm_filter_phase.hip
+void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *plan, std::vector<int32_t> *table);
+template <typename TI, typename TO>
+int launch_phase(const parrm_filter_plan *plan, FilterArgs a, hipStream_t stream);
+}  // namespace parrm_filter

@@ -31,6 +31,8 @@ def _variants(plan):
     out = [_hip.KERNEL_GATHER]
     if plan.info.stride > 0:
         out.append(_hip.KERNEL_STRIDE)
+    if plan.info.phase_groups > 0:
+        out.append(_hip.KERNEL_PHASE)
     return out
 
 
@@ -137,7 +139,7 @@ def test_filter_strided_rows_and_auto_kernel():
     d_big = torch.from_numpy(big).cuda()
     view = d_big[:, 1000:81001]  # row stride 90000, 80001 samples, 8-byte-aligned only
     plan = _hip.FilterPlan(filt)
-    assert plan.info.kernel == _hip.KERNEL_STRIDE
+    assert plan.info.kernel == _hip.KERNEL_PHASE
     y = plan.apply(view).cpu().numpy()
     _assert_filter_close(y, orc.filter_data_direct(big[:, 1000:81001], filt))
     out = torch.zeros((6, 100000), dtype=torch.float64, device="cuda")
