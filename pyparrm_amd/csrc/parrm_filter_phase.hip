@@ -42,52 +42,89 @@ __device__ inline unsigned lds_offset(const void *p) {
         (const __attribute__((address_space(3))) void *)p));
 }
 
-// R separate full-rate LDS reads of consecutive elements starting at byte address `addr`.
-template <typename TI, int R>
-__device__ inline void lds_read_rows(unsigned addr, TI (&v)[R]) {
-    static_assert(R >= 2 && R <= 4, "R");
-    if constexpr (sizeof(TI) == 8) {
-        if constexpr (R == 2)
-            asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr));
-        else if constexpr (R == 3)
-            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16"
-                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                         : "v"(addr));
-        else
-            asm volatile(
-                "ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
-                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                : "v"(addr));
-    } else {
-        if constexpr (R == 2)
-            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4" : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr));
-        else if constexpr (R == 3)
-            asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8"
-                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                         : "v"(addr));
-        else
-            asm volatile(
-                "ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12"
-                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                : "v"(addr));
-    }
-}
+// ---- tap reads -------------------------------------------------------------------------------
+// A batch is 2*TB row-sets (TB taps of each sign) of R consecutive elements: 2*TB*R separate
+// full-rate ds_read_b64 / ds_read_b32 with immediate offsets.  They go through inline asm because
+// hipcc would pair adjacent-row reads into ds_read2_b64, which moves 16 B/lane at HALF the
+// ds_read_b64 rate (MI355X_MICROARCH.md, LDS table).  The reads are software-pipelined: the asm
+// that issues batch k also waits, with a COUNTED lgkmcnt, for batch k-1 -- LDS operations return
+// in order, so "at most n outstanding" right after issuing n reads means everything older is
+// back, whatever else (LDS or scalar loads) the compiler had in flight before the statement.
+// The LDS pipe therefore never drains inside the tap loop (draining every batch measured ~45 %
+// of the LDS rate at 3 waves/SIMD).  Uses of a batch are kept below its wait by a
+// sched_barrier (the compiler does not know the asm results are asynchronous).
+template <int R>
+struct TapBatch {
+    static constexpr int TB = R <= 3 ? 2 : 1;  // taps per sign per batch; 2*TB*R <= 12 (lgkmcnt is 4 bits)
+    static constexpr int N = 2 * TB * R;
+};
 
-// s_waitcnt lgkmcnt(0) that the four row-sets are data-dependent on (so no use can be hoisted
-// above it).  lgkmcnt(0) is safe whatever else the compiler has in flight.
-template <typename TI, int R>
-__device__ inline void lds_wait_rows(TI (&a)[R], TI (&b)[R], TI (&c)[R], TI (&d)[R]) {
-    if constexpr (R == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]), "+v"(d[0]), "+v"(d[1]));
-    else if constexpr (R == 3)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(c[0]), "+v"(c[1]),
-                       "+v"(c[2]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
-                       "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#define PARRM_RD3(op, o0, o1, o2, a, s) \
+    op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t" op " %" #o2 ", %" #a " offset:2*" #s "\n\t"
+#define PARRM_RD2(op, o0, o1, a, s) op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t"
+#define PARRM_RD4(op, o0, o1, o2, o3, a, s)                                                              \
+    op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t" op " %" #o2 ", %" #a " offset:2*" #s \
+       "\n\t" op " %" #o3 ", %" #a " offset:3*" #s "\n\t"
+
+// v[j][i]: row-set j (0..2*TB-1), row i.  WAIT: also wait for everything issued before this batch.
+template <typename TI, int R, bool WAIT>
+__device__ inline void tap_batch(const unsigned (&ad)[2 * TapBatch<R>::TB], TI (&v)[2 * TapBatch<R>::TB][R]) {
+    if constexpr (sizeof(TI) == 8 && R == 3) {
+#define PARRM_BODY(w)                                                                                       \
+    asm volatile(PARRM_RD3("ds_read_b64", 0, 1, 2, 12, 8) PARRM_RD3("ds_read_b64", 3, 4, 5, 13, 8)           \
+                     PARRM_RD3("ds_read_b64", 6, 7, 8, 14, 8) PARRM_RD3("ds_read_b64", 9, 10, 11, 15, 8) w   \
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[1][0]), "=&v"(v[1][1]),           \
+                   "=&v"(v[1][2]), "=&v"(v[2][0]), "=&v"(v[2][1]), "=&v"(v[2][2]), "=&v"(v[3][0]),           \
+                   "=&v"(v[3][1]), "=&v"(v[3][2])                                                           \
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
+        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(12)"); else PARRM_BODY("");
+#undef PARRM_BODY
+    } else if constexpr (sizeof(TI) == 4 && R == 3) {
+#define PARRM_BODY(w)                                                                                       \
+    asm volatile(PARRM_RD3("ds_read_b32", 0, 1, 2, 12, 4) PARRM_RD3("ds_read_b32", 3, 4, 5, 13, 4)           \
+                     PARRM_RD3("ds_read_b32", 6, 7, 8, 14, 4) PARRM_RD3("ds_read_b32", 9, 10, 11, 15, 4) w   \
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[1][0]), "=&v"(v[1][1]),           \
+                   "=&v"(v[1][2]), "=&v"(v[2][0]), "=&v"(v[2][1]), "=&v"(v[2][2]), "=&v"(v[3][0]),           \
+                   "=&v"(v[3][1]), "=&v"(v[3][2])                                                           \
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
+        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(12)"); else PARRM_BODY("");
+#undef PARRM_BODY
+    } else if constexpr (sizeof(TI) == 8 && R == 2) {
+#define PARRM_BODY(w)                                                                                     \
+    asm volatile(PARRM_RD2("ds_read_b64", 0, 1, 8, 8) PARRM_RD2("ds_read_b64", 2, 3, 9, 8)                  \
+                     PARRM_RD2("ds_read_b64", 4, 5, 10, 8) PARRM_RD2("ds_read_b64", 6, 7, 11, 8) w          \
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]),          \
+                   "=&v"(v[2][1]), "=&v"(v[3][0]), "=&v"(v[3][1])                                          \
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
+        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
+#undef PARRM_BODY
+    } else if constexpr (sizeof(TI) == 4 && R == 2) {
+#define PARRM_BODY(w)                                                                                     \
+    asm volatile(PARRM_RD2("ds_read_b32", 0, 1, 8, 4) PARRM_RD2("ds_read_b32", 2, 3, 9, 4)                  \
+                     PARRM_RD2("ds_read_b32", 4, 5, 10, 4) PARRM_RD2("ds_read_b32", 6, 7, 11, 4) w          \
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]),          \
+                   "=&v"(v[2][1]), "=&v"(v[3][0]), "=&v"(v[3][1])                                          \
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
+        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
+#undef PARRM_BODY
+    } else if constexpr (sizeof(TI) == 8 && R == 4) {
+#define PARRM_BODY(w)                                                                                        \
+    asm volatile(PARRM_RD4("ds_read_b64", 0, 1, 2, 3, 8, 8) PARRM_RD4("ds_read_b64", 4, 5, 6, 7, 9, 8) w       \
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]),            \
+                   "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])                                            \
+                 : "v"(ad[0]), "v"(ad[1]))
+        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
+#undef PARRM_BODY
+    } else {
+        static_assert(sizeof(TI) == 4 && R == 4, "unsupported tap batch shape");
+#define PARRM_BODY(w)                                                                                        \
+    asm volatile(PARRM_RD4("ds_read_b32", 0, 1, 2, 3, 8, 4) PARRM_RD4("ds_read_b32", 4, 5, 6, 7, 9, 4) w       \
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]),            \
+                   "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])                                            \
+                 : "v"(ad[0]), "v"(ad[1]))
+        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
+#undef PARRM_BODY
+    }
 }
 
 template <typename TI, typename TO, int DP, int R>
@@ -197,17 +234,29 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     int sl_fill = (NGR - a_lo + 1 + g * R + a_hi) % M;  // slot of this wave's first prefetched row
     int par = 0;
 
-    for (int mk = 0; mk < rows_total; mk += NGR) {
+    // rows of iteration 1 are requested now (they are published during iteration 0); every
+    // iteration then requests the rows of iteration k+2, so a load has a whole iteration to land
+    TI pre_a[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int64_t n1 = s0 + static_cast<int64_t>(NGR - a_lo + 1 + g * R + i) * q + r;
+        pre_a[i] = (active && NGR < rows_total) ? load_padded(a, xrow, n1) : TI(0);
+    }
+
+    // One iteration = NG*R rows.  `pub` holds the rows requested one iteration ago (published to LDS
+    // here), `req` receives the rows of iteration k+2.  The loop below alternates two register sets so
+    // that no copy ever touches a register with a load in flight (a copy would force vmcnt(0)).
+    auto iteration = [&](const int mk, TI (&pub)[R], TI (&req)[R]) {
         const int m = mk + g * R;
         const bool more = mk + NGR < rows_total;
-        // 1. prefetch this thread's share of the next iteration's rows
-        TI pre[R];
+        const bool more2 = mk + 2 * NGR < rows_total;
+        // 1. request this thread's share of the rows iteration k+2 needs
         const int frow = mk + NGR - a_lo + 1 + g * R;
-        if (more && !(p.debug & 4)) {
 #pragma unroll
-            for (int i = 0; i < R; ++i)
-                pre[i] = active ? load_padded(a, xrow, s0 + static_cast<int64_t>(frow + i) * q + r) : TI(0);
-        }
+        for (int i = 0; i < R; ++i)
+            req[i] = (more2 && active && !(p.debug & 4))
+                           ? load_padded(a, xrow, s0 + static_cast<int64_t>(frow + NGR + i) * q + r)
+                           : TI(0);
         // 2. row sums Delta_i = sum_u d_q(u) xz[(m+i)q + r - u]
         double accp[R], accm[R];
         TI xo[R];
@@ -217,34 +266,45 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             accm[i] = 0.0;
             xo[i] = *reinterpret_cast<const TI *>(lds_raw + lane_base + (sl_own + i) * kEl);
         }
-        // Taps in batches of 4 (x2 signs x R rows = up to 32 LDS reads in flight), issued through
-        // inline asm: left to itself hipcc pairs the adjacent-row reads into ds_read2_b64, which
-        // moves 16 B/lane at HALF the ds_read_b64 rate (MI355X_MICROARCH.md, LDS table) and makes
-        // the kernel LDS-bound.  The asm reads are invisible to the compiler's waitcnt pass, so the
-        // batch ends with an explicit lgkmcnt(0) that every value is threaded through.
         const unsigned lds0 = lds_offset(lds_raw) + static_cast<unsigned>(lane_base);
-        if (!(p.debug & 1))
+        if (!(p.debug & 1)) {
+            constexpr int TB = TapBatch<R>::TB;
+            constexpr int NB = DP / TB;
+            static_assert(DP % TB == 0, "DP must be a multiple of the batch size");
+            TI v[2][2 * TB][R];
+            auto addresses = [&](int k, unsigned (&ad)[2 * TB]) {
 #pragma unroll
-        for (int t0 = 0; t0 < DP; t0 += 4) {
-            TI vp[4][R], vm[4][R];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int sp = sl_top - tp_a[t0 + t];
-                sp += (sp >> 31) & M;
-                lds_read_rows<TI, R>(lds0 + static_cast<unsigned>(sp * kEl + tp_c[t0 + t]), vp[t]);
-                int sm = sl_top - tm_a[t0 + t];
-                sm += (sm >> 31) & M;
-                lds_read_rows<TI, R>(lds0 + static_cast<unsigned>(sm * kEl + tm_c[t0 + t]), vm[t]);
-            }
-            lds_wait_rows<TI, R>(vp[0], vm[0], vp[1], vm[1]);
-            lds_wait_rows<TI, R>(vp[2], vm[2], vp[3], vm[3]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    accp[i] += static_cast<double>(vp[t][i]);
-                    accm[i] += static_cast<double>(vm[t][i]);
+                for (int t = 0; t < TB; ++t) {
+                    int sp = sl_top - tp_a[k * TB + t];
+                    sp += (sp >> 31) & M;
+                    ad[2 * t] = lds0 + static_cast<unsigned>(sp * kEl + tp_c[k * TB + t]);
+                    int sm = sl_top - tm_a[k * TB + t];
+                    sm += (sm >> 31) & M;
+                    ad[2 * t + 1] = lds0 + static_cast<unsigned>(sm * kEl + tm_c[k * TB + t]);
                 }
+            };
+            auto accumulate = [&](TI (&b)[2 * TB][R]) {
+#pragma unroll
+                for (int t = 0; t < TB; ++t)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        accp[i] += static_cast<double>(b[2 * t][i]);
+                        accm[i] += static_cast<double>(b[2 * t + 1][i]);
+                    }
+            };
+            unsigned ad[2 * TB];
+            addresses(0, ad);
+            tap_batch<TI, R, false>(ad, v[0]);
+#pragma unroll
+            for (int k = 1; k < NB; ++k) {
+                addresses(k, ad);
+                tap_batch<TI, R, true>(ad, v[k & 1]);  // issues batch k, returns once batch k-1 is back
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(v[(k - 1) & 1]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(v[(NB - 1) & 1]);
         }
         double delta[R];
         double tot = 0.0;
@@ -254,16 +314,18 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             tot += delta[i];
         }
         xchg[(par * NG + g) * QP + r] = tot;
-        // 3. publish the prefetched rows (their slots alias rows older than mk - a_hi)
+        // 3. publish the rows requested one iteration ago (their slots alias rows older than mk - a_hi)
         if (more && active && !(p.debug & 4)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 int sl = sl_fill + i;
                 if (sl >= M) sl -= M;
-                store_cells(frow + i, sl, r, pre[i]);
+                store_cells(frow + i, sl, r, pub[i]);
             }
         }
-        if (!(p.debug & 8)) __syncthreads();
+        // LDS-only barrier: a plain __syncthreads() also waits vmcnt(0), i.e. for the global loads
+        // requested above and for the previous iteration's output stores, once per iteration
+        if (!(p.debug & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // 4. chain the groups: S at this wave's first row, and S at the next iteration's base row
         double s_row = S, s_all = 0.0;
         for (int gg = 0; gg < NG; ++gg) {
@@ -288,11 +350,16 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         if (sl_own >= M) sl_own -= M;
         sl_fill += NGR;
         if (sl_fill >= M) sl_fill -= M;
+    };
+    TI pre_b[R];
+    for (int mk = 0; mk < rows_total; mk += 2 * NGR) {
+        iteration(mk, pre_a, pre_b);
+        if (mk + NGR < rows_total) iteration(mk + NGR, pre_b, pre_a);
     }
 }
 
 int pad_half(int64_t n) {
-    for (int d : {4, 8, 12, 16, 24, 32})
+    for (int d : {4, 8, 12, 14, 16, 20, 24, 32})
         if (n <= d) return d;
     return 0;
 }
@@ -457,6 +524,8 @@ int launch_phase(const parrm_filter_plan *plan, FilterArgs a, hipStream_t stream
         case 4: return launch_phase_r<TI, TO, 4>(plan, a, g, stream);
         case 8: return launch_phase_r<TI, TO, 8>(plan, a, g, stream);
         case 12: return launch_phase_r<TI, TO, 12>(plan, a, g, stream);
+        case 14: return launch_phase_r<TI, TO, 14>(plan, a, g, stream);
+        case 20: return launch_phase_r<TI, TO, 20>(plan, a, g, stream);
         case 16: return launch_phase_r<TI, TO, 16>(plan, a, g, stream);
         case 24: return launch_phase_r<TI, TO, 24>(plan, a, g, stream);
         case 32: return launch_phase_r<TI, TO, 32>(plan, a, g, stream);
