@@ -1,0 +1,155 @@
+"""One-dimensional Nelder-Mead with SciPy's exact semantics, restructured for a GPU objective.
+
+The reference refines period estimates with ``scipy.optimize.fmin`` (parrm.py:510-517, :545-550):
+~35 strictly sequential objective evaluations per start, five starts per stage.  On the device one
+evaluation is latency-bound (three small launches + one read-back), so the sequential count -- not
+the arithmetic -- sets the time.  This module keeps SciPy's decisions bit-for-bit
+(``scipy/optimize/_optimize.py::_minimize_neldermead``, N = 1, adaptive=False: rho 1, chi 2,
+psi 0.5, sigma 0.5, initial simplex {x0, 1.05*x0}, xatol = fatol = 1e-4, maxiter = maxfun = 200)
+but changes HOW the objective is called:
+
+* speculation: in 1-D an iteration evaluates the reflection and then at most one of
+  {expansion, outside contraction, inside contraction} and possibly the shrink point.  All five
+  abscissae are known at the start of the iteration, so they are evaluated as ONE batch and the
+  iteration's branches then only read the results they would have computed;
+* lock-step starts: independent starts advance one iteration per batch, so a stage costs
+  max(iterations) batches instead of sum(evaluations) launches.
+
+Function-call accounting follows SciPy (only the evaluations SciPy would have made are counted
+against ``maxfun``), so termination is identical.  tests/test_neldermead.py checks equality of
+(xopt, fopt, iterations, funcalls) with ``scipy.optimize.fmin`` on deterministic objectives.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+RHO, CHI, PSI, SIGMA = 1, 2, 0.5, 0.5
+NONZDELT, ZDELT = 0.05, 0.00025
+
+
+class _MaxFun(Exception):
+    pass
+
+
+class _Start:
+    """State of one SciPy Nelder-Mead run on a scalar parameter."""
+
+    def __init__(self, x0, xatol, fatol, maxiter, maxfun):
+        x0 = np.atleast_1d(x0).flatten()
+        if not np.issubdtype(x0.dtype, np.inexact):
+            x0 = x0.astype(np.float64)
+        if x0.shape[0] != 1:
+            raise ValueError("only scalar parameters are supported")
+        self.xatol, self.fatol = xatol, fatol
+        self.maxiter = 200 if maxiter is None else maxiter
+        self.maxfun = 200 if maxfun is None else maxfun
+        y = x0[0] * (1 + NONZDELT) if x0[0] != 0 else x0.dtype.type(ZDELT)
+        self.sim = np.array([x0[0], y], dtype=x0.dtype)
+        self.fsim = np.full(2, np.inf)
+        self.fcalls = 0
+        self.iterations = 0  # 0: initial simplex not evaluated yet
+        self.done = False
+
+    # -- the abscissae the next step may need -------------------------------------------------
+    def wanted(self):
+        if self.iterations == 0:
+            return [self.sim[0], self.sim[1]]
+        xbar, worst = self.sim[0], self.sim[1]
+        self._xr = (1 + RHO) * xbar - RHO * worst
+        self._xe = (1 + RHO * CHI) * xbar - RHO * CHI * worst
+        self._xc = (1 + PSI * RHO) * xbar - PSI * RHO * worst
+        self._xcc = (1 - PSI) * xbar + PSI * worst
+        self._xs = self.sim[0] + SIGMA * (self.sim[1] - self.sim[0])
+        return [self._xr, self._xe, self._xc, self._xcc, self._xs]
+
+    def _f(self, table, x):
+        if self.fcalls >= self.maxfun:  # SciPy's wrapper refuses the call
+            raise _MaxFun()
+        self.fcalls += 1
+        x = float(x)
+        return table[x] if x == x else float("nan")
+
+    def _sort(self):
+        ind = np.argsort(self.fsim)
+        self.sim = np.take(self.sim, ind, 0)
+        self.fsim = np.take(self.fsim, ind, 0)
+
+    # -- one SciPy step, reading the speculative results --------------------------------------
+    def advance(self, table):
+        if self.iterations == 0:
+            try:
+                for k in range(2):
+                    self.fsim[k] = self._f(table, self.sim[k])
+            except _MaxFun:
+                pass
+            self._sort()
+            self.iterations = 1
+        else:
+            sim, fsim = self.sim, self.fsim
+            try:
+                fxr = self._f(table, self._xr)
+                doshrink = False
+                if fxr < fsim[0]:
+                    fxe = self._f(table, self._xe)
+                    if fxe < fxr:
+                        sim[-1], fsim[-1] = self._xe, fxe
+                    else:
+                        sim[-1], fsim[-1] = self._xr, fxr
+                else:  # fsim[0] <= fxr; with one parameter fsim[-2] is fsim[0], so no plain accept
+                    if fxr < fsim[-2]:
+                        sim[-1], fsim[-1] = self._xr, fxr
+                    else:
+                        if fxr < fsim[-1]:
+                            fxc = self._f(table, self._xc)
+                            if fxc <= fxr:
+                                sim[-1], fsim[-1] = self._xc, fxc
+                            else:
+                                doshrink = True
+                        else:
+                            fxcc = self._f(table, self._xcc)
+                            if fxcc < fsim[-1]:
+                                sim[-1], fsim[-1] = self._xcc, fxcc
+                            else:
+                                doshrink = True
+                        if doshrink:
+                            sim[1] = self._xs
+                            fsim[1] = self._f(table, self._xs)
+                self.iterations += 1
+            except _MaxFun:
+                pass
+            self._sort()
+        self._check_done()
+
+    def _check_done(self):
+        if not (self.fcalls < self.maxfun and self.iterations < self.maxiter):
+            self.done = True
+        else:
+            with np.errstate(invalid="ignore"):
+                if (np.max(np.abs(self.sim[1:] - self.sim[0])) <= self.xatol
+                        and np.max(np.abs(self.fsim[0] - self.fsim[1:])) <= self.fatol):
+                    self.done = True
+
+    def result(self):
+        return self.sim[:1].copy(), float(np.min(self.fsim)), self.iterations, self.fcalls
+
+
+def fmin_lockstep(objective_batch, starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None):
+    """Run one SciPy-equivalent ``fmin`` per entry of ``starts``, advancing all of them together.
+
+    ``objective_batch(x: float64[n]) -> float64[n]`` evaluates the objective at every abscissa of
+    a batch.  Returns a list of ``(xopt[1], fopt, iterations, funcalls)`` in the order of
+    ``starts`` -- what ``fmin(..., full_output=True)[:4]`` returns.
+    """
+    runs = [_Start(x0, xtol, ftol, maxiter, maxfun) for x0 in starts]
+    while True:
+        active = [run for run in runs if not run.done]
+        if not active:
+            break
+        wanted = [run.wanted() for run in active]
+        flat = np.array(sorted({float(x) for xs in wanted for x in xs if x == x}), dtype=np.float64)
+        values = np.asarray(objective_batch(flat), dtype=np.float64)
+        table = dict(zip(flat.tolist(), values.tolist()))
+        for run in active:
+            run.advance(table)
+    return [run.result() for run in runs]

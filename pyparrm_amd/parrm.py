@@ -7,7 +7,8 @@ reference tests pin, ``tests/test_parrm.py:112-330``), same call-order state mac
 
 * ``find_period``  -> device: statistics pass, column gather, batched harmonic-regression
   objective (``parrm_absdiff_mean`` / ``parrm_gather_standardise`` / ``parrm_fit_errors``); host:
-  index draws, candidate grids and ``scipy.optimize.fmin`` exactly as the reference calls them.
+  index draws and candidate grids with the reference's NumPy expressions, and a Nelder-Mead that
+  makes SciPy ``fmin``'s decisions but evaluates its candidates in device batches.
 * ``create_filter`` -> host (microseconds; the tap set is a step function of the period, so it is
   built with the same NumPy expressions to stay bit-identical, parrm.py:803-833).
 * ``filter_data``  -> device: closed-form phase-neighbour stencil (``parrm_filter_apply``).
@@ -22,9 +23,8 @@ from __future__ import annotations
 from multiprocessing import cpu_count
 
 import numpy as np
-from scipy.optimize import fmin
-
 from . import _hip
+from ._neldermead import fmin_lockstep
 
 _PERIOD_FAILURE = (
     "The period cannot be estimated from the data. Check that your data "
@@ -264,9 +264,8 @@ class PARRM:
             y, d_idx = self._stage_matrix(indices)
             stage = (y, d_idx)
 
-            def objective(period, _y=y, _i=d_idx, _bw=bandwidth):
-                # `period` is a float64 scalar (grid) or a shape-(1,) array (fmin), parrm.py:578-581
-                return float(_hip.fit_errors(_y, _i, np.asarray(period), _bw, _STAGE_LAMBDA, ws)[0])
+            def objective(periods, _y=y, _i=d_idx, _bw=bandwidth):
+                return _hip.fit_errors(_y, _i, periods, _bw, _STAGE_LAMBDA, ws)
 
             grid = self._get_possible_periods(estimate, run)
             errors = _hip.fit_errors(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, ws)
@@ -283,10 +282,10 @@ class PARRM:
         y, d_idx = stage
         final_bw = _STAGE_BANDWIDTHS[-1]
 
-        def final_objective(period):
-            return float(_hip.fit_errors(y, d_idx, np.asarray(period), final_bw, 0.0, ws)[0])
+        def final_objective(periods):
+            return _hip.fit_errors(y, d_idx, periods, final_bw, 0.0, ws)
 
-        self._period = fmin(final_objective, estimate[0], disp=False)[0]
+        self._period = fmin_lockstep(final_objective, [estimate[0]])[0][0][0]
         self._trace = trace
 
     def _get_centre_indices(self, use_n_samples, ignore_portion, random_state) -> np.ndarray:
@@ -525,10 +524,13 @@ def _rank_candidates(periods: np.ndarray, errors: np.ndarray):
 
 
 def _refine_candidates(periods: np.ndarray, errors: np.ndarray, objective) -> tuple:
-    """Nelder-Mead (SciPy defaults) from the best <= 5 candidates; keep the overall arg-min
-    (parrm.py:467-522).  ``errors`` may be longer than ``periods`` (non-finite tail)."""
-    for i in range(int(np.min((5, periods.shape[0])))):
-        xopt, fopt = fmin(objective, periods[i], full_output=True, disp=False)[:2]
+    """Nelder-Mead (SciPy ``fmin`` defaults) from the best <= 5 candidates; keep the overall
+    arg-min (parrm.py:467-522).  ``errors`` may be longer than ``periods`` (non-finite tail).
+    The starts are independent in the reference too (an ordered map, :510-517); here they advance
+    in lock-step so that each device batch serves all of them (``_neldermead.fmin_lockstep``)."""
+    n_starts = int(np.min((5, periods.shape[0])))
+    results = fmin_lockstep(objective, [periods[i] for i in range(n_starts)])
+    for i, (xopt, fopt, _, _) in enumerate(results):
         periods[i] = xopt[0]
         errors[i] = fopt
     return (periods[errors.argmin()],)

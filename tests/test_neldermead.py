@@ -1,0 +1,72 @@
+"""The batched Nelder-Mead must make exactly the decisions of ``scipy.optimize.fmin`` (the
+optimiser the reference calls, parrm.py:510-517,545-550): same iterates, same call counts."""
+
+import numpy as np
+import pytest
+from scipy.optimize import fmin
+
+from pyparrm_amd._neldermead import fmin_lockstep
+
+
+def _objectives():
+    def smooth(x):
+        return (x - 3.3) ** 2 + 0.1 * np.sin(40 * x)
+
+    def quantised(x):  # plateaus and ties: exercises contraction / shrink branches
+        return np.round((x - 7.742) ** 2 * 50) / 50 + 1e-3 * np.abs(x)
+
+    def spiky(x):
+        return np.abs(np.sin(3 * x)) + 0.01 * (x - 2) ** 2
+
+    def with_inf(x):
+        return np.inf if x > 5.2 else (x - 5) ** 2
+
+    def period_like(x):  # narrow minimum on a flat floor, like the PARRM objective
+        return 1.0 - 0.6 * np.exp(-(((x - 169.2358) / 2e-3) ** 2))
+
+    return [smooth, quantised, spiky, with_inf, period_like]
+
+
+@pytest.mark.parametrize("fi", range(5))
+def test_matches_scipy_fmin_single_start(fi):
+    f = _objectives()[fi]
+    starts = [0.7, 2.9, 5.0, 7.7, 169.2, 169.236, -3.0, 0.0, 1e-3]
+    for x0 in starts:
+        ref = fmin(lambda x: float(f(x[0])), x0, full_output=True, disp=False)
+        got = fmin_lockstep(lambda xs: np.array([f(x) for x in xs]), [x0])[0]
+        assert got[0].shape == (1,)
+        assert got[0][0] == ref[0][0], (x0, got, ref[:4])
+        assert got[1] == ref[1]
+        assert got[2] == ref[2] and got[3] == ref[3]  # iterations, funcalls
+
+
+def test_lockstep_equals_independent_runs_and_batches():
+    f = _objectives()[0]
+    starts = [0.7, 2.9, 3.31, 5.0, 10.0]
+    batches = []
+
+    def batch(xs):
+        batches.append(len(xs))
+        return np.array([f(x) for x in xs])
+
+    together = fmin_lockstep(batch, starts)
+    for x0, got in zip(starts, together):
+        ref = fmin(lambda x: float(f(x[0])), x0, full_output=True, disp=False)
+        assert got[0][0] == ref[0][0] and got[1] == ref[1] and got[3] == ref[3]
+    # one batch per lock-step iteration: far fewer device round trips than evaluations
+    assert len(batches) == max(r[2] for r in together)
+    assert sum(r[3] for r in together) > 3 * len(batches)
+
+
+def test_numpy_scalar_and_array_starts():
+    f = _objectives()[4]
+    a = fmin_lockstep(lambda xs: np.array([f(x) for x in xs]), [np.float64(169.2)])[0]
+    b = fmin_lockstep(lambda xs: np.array([f(x) for x in xs]), [np.array([169.2])])[0]
+    assert a[0][0] == b[0][0] and isinstance(a[0][0], np.float64)
+
+
+def test_maxfun_termination_matches_scipy():
+    f = _objectives()[2]
+    ref = fmin(lambda x: float(f(x[0])), 0.4, full_output=True, disp=False, maxfun=11)
+    got = fmin_lockstep(lambda xs: np.array([f(x) for x in xs]), [0.4], maxfun=11, maxiter=np.inf)[0]
+    assert got[0][0] == ref[0][0] and got[1] == ref[1] and got[3] == ref[3]
