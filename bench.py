@@ -106,6 +106,7 @@ def main():
     import torch
 
     from pyparrm_amd import PARRM, _hip
+    from pyparrm_amd.sharding import timed_steps
     from pyparrm_amd.synth import synth_recording_device
 
     _hip.require_gpu()
@@ -148,24 +149,13 @@ def main():
             timings["filter_total"].append(t2 - t1)
             timings["filter_kernel"].append(ev0.elapsed_time(ev1) * 1e-3)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # W untimed warm-up steps, then exactly K steps between two sync+barrier fences; MAX over ranks
+    elapsed = timed_steps(lambda: step(True), args.steps, 0, dist=dist, sync=torch.cuda.synchronize) \
+        if args.warmup == 0 else None
+    if elapsed is None:
+        for _ in range(args.warmup):
+            step(False)
+        elapsed = timed_steps(lambda: step(True), args.steps, 0, dist=dist, sync=torch.cuda.synchronize)
 
     if rank == 0:
         total_samples = world * n_chans * n_samples * args.steps
@@ -203,10 +193,12 @@ def main():
                 ),
                 "parallelism": f"{world} independent recordings, one per GPU, no collectives",
                 "filter": {"half_width": int(info.half_width), "taps": int(info.n_taps),
-                           "stride_q": int(info.stride), "delta_taps": int(info.n_delta)},
+                           "stride_q": int(info.phase_stride or info.stride),
+                           "delta_taps": int(info.phase_delta or info.n_delta),
+                           "row_groups": int(info.phase_groups), "rows_per_thread": int(info.phase_rows)},
             },
             "roofline": {
-                "kernel": "filter_stride_kernel<double,double>",
+                "kernel": {1: "filter_gather_kernel", 2: "filter_stride_kernel", 3: "filter_phase_kernel"}[int(info.kernel)] + "<double,double>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
