@@ -53,77 +53,57 @@ __device__ inline unsigned lds_offset(const void *p) {
 // The LDS pipe therefore never drains inside the tap loop (draining every batch measured ~45 %
 // of the LDS rate at 3 waves/SIMD).  Uses of a batch are kept below its wait by a
 // sched_barrier (the compiler does not know the asm results are asynchronous).
-template <int R>
-struct TapBatch {
-    static constexpr int TB = R <= 3 ? 2 : 1;  // taps per sign per batch; 2*TB*R <= 12 (lgkmcnt is 4 bits)
-    static constexpr int N = 2 * TB * R;
-};
-
+#define PARRM_RD2(op, o0, o1, a, s) op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t"
 #define PARRM_RD3(op, o0, o1, o2, a, s) \
     op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t" op " %" #o2 ", %" #a " offset:2*" #s "\n\t"
-#define PARRM_RD2(op, o0, o1, a, s) op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t"
 #define PARRM_RD4(op, o0, o1, o2, o3, a, s)                                                              \
     op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t" op " %" #o2 ", %" #a " offset:2*" #s \
        "\n\t" op " %" #o3 ", %" #a " offset:3*" #s "\n\t"
-
-// v[j][i]: row-set j (0..2*TB-1), row i.  WAIT: also wait for everything issued before this batch.
-template <typename TI, int R, bool WAIT>
-__device__ inline void tap_batch(const unsigned (&ad)[2 * TapBatch<R>::TB], TI (&v)[2 * TapBatch<R>::TB][R]) {
-    if constexpr (sizeof(TI) == 8 && R == 3) {
-#define PARRM_BODY(w)                                                                                       \
-    asm volatile(PARRM_RD3("ds_read_b64", 0, 1, 2, 12, 8) PARRM_RD3("ds_read_b64", 3, 4, 5, 13, 8)           \
-                     PARRM_RD3("ds_read_b64", 6, 7, 8, 14, 8) PARRM_RD3("ds_read_b64", 9, 10, 11, 15, 8) w   \
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[1][0]), "=&v"(v[1][1]),           \
-                   "=&v"(v[1][2]), "=&v"(v[2][0]), "=&v"(v[2][1]), "=&v"(v[2][2]), "=&v"(v[3][0]),           \
-                   "=&v"(v[3][1]), "=&v"(v[3][2])                                                           \
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
-        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(12)"); else PARRM_BODY("");
-#undef PARRM_BODY
+// One row-set = R consecutive elements of one tap.  WAIT = n: after issuing, wait until at most n
+// LDS operations are outstanding (n = 3*R keeps three row-sets in flight; lgkmcnt is 4 bits).
+#define PARRM_WAITSTR(n) "s_waitcnt lgkmcnt(" #n ")"
+template <typename TI, int R, int WAIT>
+__device__ inline void tap_rows(unsigned ad, TI (&v)[R]) {
+    static_assert(WAIT == -1 || WAIT == 6 || WAIT == 9 || WAIT == 12, "wait count");
+    if constexpr (sizeof(TI) == 8 && R == 4) {
+        if constexpr (WAIT == 12)
+            asm volatile(PARRM_RD4("ds_read_b64", 0, 1, 2, 3, 4, 8) PARRM_WAITSTR(12)
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad));
+        else
+            asm volatile(PARRM_RD4("ds_read_b64", 0, 1, 2, 3, 4, 8) ""
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad));
+    } else if constexpr (sizeof(TI) == 4 && R == 4) {
+        if constexpr (WAIT == 12)
+            asm volatile(PARRM_RD4("ds_read_b32", 0, 1, 2, 3, 4, 4) PARRM_WAITSTR(12)
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad));
+        else
+            asm volatile(PARRM_RD4("ds_read_b32", 0, 1, 2, 3, 4, 4) ""
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad));
+    } else if constexpr (sizeof(TI) == 8 && R == 3) {
+        if constexpr (WAIT == 9)
+            asm volatile(PARRM_RD3("ds_read_b64", 0, 1, 2, 3, 8) PARRM_WAITSTR(9)
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
+        else
+            asm volatile(PARRM_RD3("ds_read_b64", 0, 1, 2, 3, 8) ""
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
     } else if constexpr (sizeof(TI) == 4 && R == 3) {
-#define PARRM_BODY(w)                                                                                       \
-    asm volatile(PARRM_RD3("ds_read_b32", 0, 1, 2, 12, 4) PARRM_RD3("ds_read_b32", 3, 4, 5, 13, 4)           \
-                     PARRM_RD3("ds_read_b32", 6, 7, 8, 14, 4) PARRM_RD3("ds_read_b32", 9, 10, 11, 15, 4) w   \
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[1][0]), "=&v"(v[1][1]),           \
-                   "=&v"(v[1][2]), "=&v"(v[2][0]), "=&v"(v[2][1]), "=&v"(v[2][2]), "=&v"(v[3][0]),           \
-                   "=&v"(v[3][1]), "=&v"(v[3][2])                                                           \
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
-        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(12)"); else PARRM_BODY("");
-#undef PARRM_BODY
+        if constexpr (WAIT == 9)
+            asm volatile(PARRM_RD3("ds_read_b32", 0, 1, 2, 3, 4) PARRM_WAITSTR(9)
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
+        else
+            asm volatile(PARRM_RD3("ds_read_b32", 0, 1, 2, 3, 4) ""
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
     } else if constexpr (sizeof(TI) == 8 && R == 2) {
-#define PARRM_BODY(w)                                                                                     \
-    asm volatile(PARRM_RD2("ds_read_b64", 0, 1, 8, 8) PARRM_RD2("ds_read_b64", 2, 3, 9, 8)                  \
-                     PARRM_RD2("ds_read_b64", 4, 5, 10, 8) PARRM_RD2("ds_read_b64", 6, 7, 11, 8) w          \
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]),          \
-                   "=&v"(v[2][1]), "=&v"(v[3][0]), "=&v"(v[3][1])                                          \
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
-        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
-#undef PARRM_BODY
-    } else if constexpr (sizeof(TI) == 4 && R == 2) {
-#define PARRM_BODY(w)                                                                                     \
-    asm volatile(PARRM_RD2("ds_read_b32", 0, 1, 8, 4) PARRM_RD2("ds_read_b32", 2, 3, 9, 4)                  \
-                     PARRM_RD2("ds_read_b32", 4, 5, 10, 4) PARRM_RD2("ds_read_b32", 6, 7, 11, 4) w          \
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]),          \
-                   "=&v"(v[2][1]), "=&v"(v[3][0]), "=&v"(v[3][1])                                          \
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]))
-        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
-#undef PARRM_BODY
-    } else if constexpr (sizeof(TI) == 8 && R == 4) {
-#define PARRM_BODY(w)                                                                                        \
-    asm volatile(PARRM_RD4("ds_read_b64", 0, 1, 2, 3, 8, 8) PARRM_RD4("ds_read_b64", 4, 5, 6, 7, 9, 8) w       \
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]),            \
-                   "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])                                            \
-                 : "v"(ad[0]), "v"(ad[1]))
-        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
-#undef PARRM_BODY
+        if constexpr (WAIT == 6)
+            asm volatile(PARRM_RD2("ds_read_b64", 0, 1, 2, 8) PARRM_WAITSTR(6) : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
+        else
+            asm volatile(PARRM_RD2("ds_read_b64", 0, 1, 2, 8) "" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
     } else {
-        static_assert(sizeof(TI) == 4 && R == 4, "unsupported tap batch shape");
-#define PARRM_BODY(w)                                                                                        \
-    asm volatile(PARRM_RD4("ds_read_b32", 0, 1, 2, 3, 8, 4) PARRM_RD4("ds_read_b32", 4, 5, 6, 7, 9, 4) w       \
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]),            \
-                   "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])                                            \
-                 : "v"(ad[0]), "v"(ad[1]))
-        if constexpr (WAIT) PARRM_BODY("s_waitcnt lgkmcnt(8)"); else PARRM_BODY("");
-#undef PARRM_BODY
+        static_assert(sizeof(TI) == 4 && R == 2, "unsupported row-set shape");
+        if constexpr (WAIT == 6)
+            asm volatile(PARRM_RD2("ds_read_b32", 0, 1, 2, 4) PARRM_WAITSTR(6) : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
+        else
+            asm volatile(PARRM_RD2("ds_read_b32", 0, 1, 2, 4) "" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
     }
 }
 
@@ -131,26 +111,19 @@ template <typename TI, typename TO, int DP, int R>
 __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseGeom p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int kEl = static_cast<int>(sizeof(TI));
+    constexpr int kElLog2 = kEl == 8 ? 3 : 2;
     const int q = p.q, QP = p.qp, B = p.guard, M = p.m_slots, RS = p.rs, NG = p.n_groups;
     const int a_lo = p.a_lo, a_hi = p.a_hi;
     const int NGR = NG * R;
     const int tid = threadIdx.x;
     const int g = __builtin_amdgcn_readfirstlane(tid / QP);  // whole waves per group
     const int r = tid - g * QP;
-    const bool active = r < q;
+    const bool active = r < q;            // compute lane: owns residue r
+    const bool filler = r < q + 2 * B;    // fill lane: owns cell column rho (idle lanes take the halo)
+    const int rho = r < q + B ? r : r - q - 2 * B;  // extended residue in [-B, q+B)
     const int n_res = q + 2 * B;
     double *xchg = reinterpret_cast<double *>(lds_raw + align16(static_cast<size_t>(n_res) * RS * kEl));
-
-    // wave-uniform tap tables (scalar registers)
-    int tp_a[DP], tp_c[DP], tm_a[DP], tm_c[DP];
-#pragma unroll
-    for (int t = 0; t < DP; ++t) {
-        tp_a[t] = p.tab[t];
-        tp_c[t] = -p.tab[DP + t] * RS * kEl;
-        tm_a[t] = p.tab[2 * DP + t];
-        tm_c[t] = -p.tab[3 * DP + t] * RS * kEl;
-    }
-    const int32_t *runs = p.tab + 4 * DP;
+    const int32_t *runs = p.tab + M * 2 * DP;
 
     const int64_t blk = blockIdx.x;
     const int64_t c = blk / a.n_stretch;
@@ -161,62 +134,70 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     const int len = static_cast<int>(s1 - s0);
     const int rows_total = (len + q - 1) / q;
     const TI *xrow = static_cast<const TI *>(a.x) + c * a.ldx;
+    TO *yrow = static_cast<TO *>(a.y) + c * a.ldy - a.out_first;
+    // addressable, in-recording sample range (everything else reads as zero)
+    const int64_t ok_lo = a.buf_first > 0 ? a.buf_first : 0;
+    const int64_t ok_hi = a.buf_first + a.buf_len < a.n_total ? a.buf_first + a.buf_len : a.n_total;
 
-    // byte offset of (this residue, slot 0); idle lanes of the last wave shadow residue 0
-    const int lane_base = ((active ? r : 0) + B) * RS * kEl;
-    // slot(row) = (row + a_hi) mod M
-    auto store_cells = [&](int row, int sl, int rr, TI v) {
-        // main cell (+ mirrored head so that slot + i, i < R, never wraps)
-        TI *cell = reinterpret_cast<TI *>(lds_raw + static_cast<size_t>((rr + B) * RS + sl) * kEl);
+    // Cell (rho, row) holds sample s0 + row*q + rho for every rho in [-B, q+B): the B-wide halos are
+    // ordinary columns owned by the otherwise idle lanes of the last wave.  slot(row) = (row+a_hi) mod M.
+    const int fill_base = (rho + B) * RS * kEl;                  // byte offset of (rho, slot 0)
+    const int lane_base = ((active ? r : 0) + B) * RS * kEl;     // byte offset of (r, slot 0)
+    // Rows whose whole span (halos included) is addressable take a wave-uniform fast path: scalar
+    // base pointer + per-lane unsigned offset (no per-lane bounds tests).  Computed once per stretch.
+    auto floor_div = [](int64_t x, int64_t d) -> int64_t { return x >= 0 ? x / d : -((-x + d - 1) / d); };
+    const int64_t row_lim = int64_t{1} << 28;
+    auto clamp_row = [&](int64_t v) -> int { return static_cast<int>(v < -row_lim ? -row_lim : (v > row_lim ? row_lim : v)); };
+    // load: first = s0 + row*q - B >= ok_lo  and  first + n_res <= ok_hi
+    const int lrow_lo = clamp_row(-floor_div(-(ok_lo - s0 + B), q));
+    const int lrow_hi = clamp_row(floor_div(ok_hi - n_res - s0 + B, q));
+    // emit: n0 = s0 + row*q >= hw, n0 + q - 1 + hw < n_total, (row + 1)*q <= len
+    const int erow_lo = clamp_row(-floor_div(-(static_cast<int64_t>(a.hw) - s0), q));
+    const int erow_hi = clamp_row(std::min<int64_t>(floor_div(a.n_total - a.hw - q - s0, q), len / q - 1));
+    const TI *xfast = xrow + (s0 - a.buf_first - B);  // wave-uniform
+    const unsigned fill_off = static_cast<unsigned>(rho + B);
+    auto load_row = [&](int row) -> TI {  // this lane's sample of `row`
+        if (row >= lrow_lo && row <= lrow_hi) return (xfast + static_cast<int64_t>(row) * q)[fill_off];
+        return load_padded(a, xrow, s0 + static_cast<int64_t>(row) * q + rho);
+    };
+    auto store_row = [&](int sl, TI v) {  // (+ mirrored head so that slot + i, i < R, never wraps)
+        TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl * kEl);
         *cell = v;
         if (sl < R - 1) cell[M] = v;
-        if (rr >= q - B) {  // also residue rr - q of the next row
-            int s2 = sl + 1;
-            if (s2 >= M) s2 -= M;
-            TI *gc = reinterpret_cast<TI *>(lds_raw + static_cast<size_t>((rr - q + B) * RS + s2) * kEl);
-            *gc = v;
-            if (s2 < R - 1) gc[M] = v;
-        }
-        if (rr < B && row > -a_hi) {  // also residue rr + q of the previous row
-            int s2 = sl - 1;
-            if (s2 < 0) s2 += M;
-            TI *gc = reinterpret_cast<TI *>(lds_raw + static_cast<size_t>((rr + q + B) * RS + s2) * kEl);
-            *gc = v;
-            if (s2 < R - 1) gc[M] = v;
-        }
     };
 
-    // prologue: rows [-a_hi, NGR - a_lo] of xz.  Eight loads per thread are issued before the first
-    // one is consumed; a load->store-per-element loop exposes one HBM latency per element.
+    // prologue: rows [-a_hi, NGR - a_lo) of xz, eight loads per lane in flight
     {
-        const int n_rows0 = NGR - a_lo + a_hi + 1;
-        const int nthr = blockDim.x;
-        const int total = n_rows0 * QP;
-        for (int base = 0; base < total; base += 8 * nthr) {
+        const int n_rows0 = NGR - a_lo + a_hi;
+        const int n_grp = blockDim.x / QP;  // == NG
+        for (int k0 = 0; k0 < n_rows0; k0 += 8 * n_grp) {
             TI v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int idx = base + j * nthr + tid;
-                const int k = idx / QP, rr = idx - k * QP;
-                v[j] = (idx < total && rr < q) ? load_padded(a, xrow, s0 + static_cast<int64_t>(k - a_hi) * q + rr) : TI(0);
+                const int k = k0 + j * n_grp + g;
+                v[j] = (k < n_rows0 && filler) ? load_row(k - a_hi) : TI(0);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int idx = base + j * nthr + tid;
-                const int k = idx / QP, rr = idx - k * QP;
-                if (idx < total && rr < q) store_cells(k - a_hi, k % M, rr, v[j]);
+                const int k = k0 + j * n_grp + g;
+                if (k < n_rows0 && filler) store_row(k % M, v[j]);
             }
         }
     }
+    // rows of iteration 1 are requested now (published during iteration 0)
+    TI pre_a[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        pre_a[i] = (filler && NGR < rows_total) ? load_row(NGR - a_lo + g * R + i) : TI(0);
     __syncthreads();
 
-    // S at row 0 for this residue: full evaluation, once per stretch (both groups, redundantly)
+    // S at row 0 for this residue: full evaluation, once per stretch (every group, redundantly)
     double S = 0.0;
     if (active) {
         double s_a = 0.0, s_b = 0.0;
         for (int k = 0; k < p.n_runs; ++k) {
             const int ra = runs[3 * k], b_lo = runs[3 * k + 1], b_hi = runs[3 * k + 2];
-            int sl = (0 - a_lo - ra + a_hi) % M;  // slot(0 - a), a = ra + a_lo
+            const int sl = (a_hi - a_lo - ra) % M;  // slot(0 - a), a = ra + a_lo
             const unsigned char *base = lds_raw + lane_base + sl * kEl;
             int b = b_lo;
             for (; b + 1 <= b_hi; b += 2) {
@@ -229,19 +210,11 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     }
 
     // scalar slot bookkeeping for this wave's first row m = mk + g*R
-    int sl_top = (g * R - a_lo + a_hi) % M;        // slot(m - a_lo): taps count down from here
-    int sl_own = (g * R + a_hi) % M;               // slot(m)
-    int sl_fill = (NGR - a_lo + 1 + g * R + a_hi) % M;  // slot of this wave's first prefetched row
+    int sl_top = (g * R - a_lo + a_hi) % M;         // slot(m - a_lo): the tap table is indexed by it
+    int sl_own = (g * R + a_hi) % M;                // slot(m)
+    int sl_fill = (NGR - a_lo + g * R + a_hi) % M;  // slot of the first row this wave publishes
     int par = 0;
-
-    // rows of iteration 1 are requested now (they are published during iteration 0); every
-    // iteration then requests the rows of iteration k+2, so a load has a whole iteration to land
-    TI pre_a[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int64_t n1 = s0 + static_cast<int64_t>(NGR - a_lo + 1 + g * R + i) * q + r;
-        pre_a[i] = (active && NGR < rows_total) ? load_padded(a, xrow, n1) : TI(0);
-    }
+    const unsigned lds0 = lds_offset(lds_raw) + static_cast<unsigned>(lane_base);
 
     // One iteration = NG*R rows.  `pub` holds the rows requested one iteration ago (published to LDS
     // here), `req` receives the rows of iteration k+2.  The loop below alternates two register sets so
@@ -250,13 +223,17 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         const int m = mk + g * R;
         const bool more = mk + NGR < rows_total;
         const bool more2 = mk + 2 * NGR < rows_total;
-        // 1. request this thread's share of the rows iteration k+2 needs
-        const int frow = mk + NGR - a_lo + 1 + g * R;
+        // tap offsets for this iteration: one table row, wave-uniform -> scalar loads
+        // (fetching the next row early, after the barrier, measured 5 % slower: register pressure)
+        int e[2 * DP];
+        const int32_t *trow = p.tab + sl_top * (2 * DP);
+#pragma unroll
+        for (int t = 0; t < 2 * DP; ++t) e[t] = trow[t];
+        // 1. request this lane's share of the rows iteration k+2 needs
+        const int frow = mk + NGR - a_lo + g * R;  // first row this wave publishes now
 #pragma unroll
         for (int i = 0; i < R; ++i)
-            req[i] = (more2 && active && !(p.debug & 4))
-                           ? load_padded(a, xrow, s0 + static_cast<int64_t>(frow + NGR + i) * q + r)
-                           : TI(0);
+            req[i] = (more2 && filler && !(p.debug & 4)) ? load_row(frow + NGR + i) : TI(0);
         // 2. row sums Delta_i = sum_u d_q(u) xz[(m+i)q + r - u]
         double accp[R], accm[R];
         TI xo[R];
@@ -266,45 +243,38 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             accm[i] = 0.0;
             xo[i] = *reinterpret_cast<const TI *>(lds_raw + lane_base + (sl_own + i) * kEl);
         }
-        const unsigned lds0 = lds_offset(lds_raw) + static_cast<unsigned>(lane_base);
         if (!(p.debug & 1)) {
-            constexpr int TB = TapBatch<R>::TB;
-            constexpr int NB = DP / TB;
-            static_assert(DP % TB == 0, "DP must be a multiple of the batch size");
-            TI v[2][2 * TB][R];
-            auto addresses = [&](int k, unsigned (&ad)[2 * TB]) {
+            // 2*DP row-sets, plus and minus interleaved; a ring of four register sets keeps three
+            // row-sets (3*R reads) in flight behind the one being accumulated
+            constexpr int NS = 2 * DP;
+            constexpr int W3 = 3 * R;
+            TI v[4][R];
+            auto addr = [&](int j) -> unsigned {  // j even: +1 tap j/2, j odd: -1 tap j/2
+                return lds0 + (static_cast<unsigned>(e[(j & 1) * DP + (j >> 1)]) << kElLog2);
+            };
+            auto accumulate = [&](int j, TI (&b)[R]) {
 #pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    int sp = sl_top - tp_a[k * TB + t];
-                    sp += (sp >> 31) & M;
-                    ad[2 * t] = lds0 + static_cast<unsigned>(sp * kEl + tp_c[k * TB + t]);
-                    int sm = sl_top - tm_a[k * TB + t];
-                    sm += (sm >> 31) & M;
-                    ad[2 * t + 1] = lds0 + static_cast<unsigned>(sm * kEl + tm_c[k * TB + t]);
+                for (int i = 0; i < R; ++i) {
+                    if (j & 1)
+                        accm[i] += static_cast<double>(b[i]);
+                    else
+                        accp[i] += static_cast<double>(b[i]);
                 }
             };
-            auto accumulate = [&](TI (&b)[2 * TB][R]) {
+            tap_rows<TI, R, -1>(addr(0), v[0]);
+            tap_rows<TI, R, -1>(addr(1), v[1]);
+            tap_rows<TI, R, -1>(addr(2), v[2]);
 #pragma unroll
-                for (int t = 0; t < TB; ++t)
-#pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        accp[i] += static_cast<double>(b[2 * t][i]);
-                        accm[i] += static_cast<double>(b[2 * t + 1][i]);
-                    }
-            };
-            unsigned ad[2 * TB];
-            addresses(0, ad);
-            tap_batch<TI, R, false>(ad, v[0]);
-#pragma unroll
-            for (int k = 1; k < NB; ++k) {
-                addresses(k, ad);
-                tap_batch<TI, R, true>(ad, v[k & 1]);  // issues batch k, returns once batch k-1 is back
+            for (int j = 3; j < NS; ++j) {
+                tap_rows<TI, R, W3>(addr(j), v[j & 3]);  // issues row-set j; returns once j-3 is back
                 __builtin_amdgcn_sched_barrier(0);
-                accumulate(v[(k - 1) & 1]);
+                accumulate(j - 3, v[(j - 3) & 3]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            accumulate(v[(NB - 1) & 1]);
+            accumulate(NS - 3, v[(NS - 3) & 3]);
+            accumulate(NS - 2, v[(NS - 2) & 3]);
+            accumulate(NS - 1, v[(NS - 1) & 3]);
         }
         double delta[R];
         double tot = 0.0;
@@ -315,12 +285,12 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         }
         xchg[(par * NG + g) * QP + r] = tot;
         // 3. publish the rows requested one iteration ago (their slots alias rows older than mk - a_hi)
-        if (more && active && !(p.debug & 4)) {
+        if (more && filler && !(p.debug & 4)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 int sl = sl_fill + i;
                 if (sl >= M) sl -= M;
-                store_cells(frow + i, sl, r, pub[i]);
+                store_row(sl, pub[i]);
             }
         }
         // LDS-only barrier: a plain __syncthreads() also waits vmcnt(0), i.e. for the global loads
@@ -334,12 +304,21 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             s_all += tg;
         }
         S += s_all;
-        // 5. outputs
-        if (active && !(p.debug & 2)) {
+        // 5. outputs.  Rows that are interior to the recording and to the stretch take a branch-free
+        // path (the test is wave-uniform); edge rows go through emit().
+        if (!(p.debug & 2)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                const int rel = (m + i) * q + r;
-                if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
+                if (m + i >= erow_lo && m + i <= erow_hi) {
+                    if (active) {
+                        double yv = static_cast<double>(xo[i]) - s_row * a.inv_taps;
+                        if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+                        (yrow + (s0 + static_cast<int64_t>(m + i) * q))[static_cast<unsigned>(r)] = static_cast<TO>(yv);
+                    }
+                } else if (active) {
+                    const int rel = (m + i) * q + r;
+                    if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
+                }
                 s_row += delta[i];
             }
         }
@@ -398,7 +377,7 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         if (!ok || nd == 0 || (nd & 1)) continue;
         const int dp = pad_half(nd / 2);
         if (dp == 0) continue;
-        const int64_t qp = (q + 63) / 64 * 64;
+        const int64_t qp = (q + 2 * guard + 63) / 64 * 64;
         // per output: 2*dp taps at (1 + R)/R vector instructions (R ~ 3) + ~20 for the epilogue
         const double cost = (2.0 * dp * 1.34 + 20.0 + 0.2 * guard) * static_cast<double>(qp) / static_cast<double>(q);
         if (cost < best_cost) {
@@ -411,7 +390,6 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     const int64_t q = best_q;
     PhaseGeom g{};
     g.q = static_cast<int32_t>(q);
-    g.qp = static_cast<int32_t>((q + 63) / 64 * 64);
     std::vector<Split> plus, minus;
     int a_lo = 0, a_hi = 0, guard = 0;
     auto note = [&](const Split &s) {
@@ -446,7 +424,10 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     g.guard = std::max(guard, 1);
     g.d_pad = pad_half(static_cast<int64_t>(plus.size()));
     g.n_runs = static_cast<int32_t>(runs.size() / 3);
-    // rows kept behind the current one: the taps' reach, but at least one iteration
+    // the 2*guard halo columns are owned by the idle lanes of the last wave of each row group
+    g.qp = static_cast<int32_t>((q + 2 * g.guard + 63) / 64 * 64);
+    g.a_lo = std::min(a_lo, 0);
+    g.a_hi = std::max(a_hi, 0);
     static const int kShapes[][2] = {{2, 4}, {2, 3}, {3, 2}, {2, 2}, {1, 4}, {1, 3}, {1, 2}};
     bool placed = false;
     for (int pass = 0; pass < 2 && !placed; ++pass) {
@@ -454,11 +435,9 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
             g.n_groups = sh[0];
             g.rows = sh[1];
             const int ngr = g.n_groups * g.rows;
-            g.a_lo = std::min(a_lo, 0);
-            // one extra row behind the taps' reach: residues r - b < 0 of the oldest row a tap can
-            // touch are mirrored from the row before it, which therefore has to be resident too
-            g.a_hi = std::max(a_hi, ngr) + 1;
-            g.m_slots = 2 * ngr + (g.a_hi - g.a_lo) + 2;
+            // rows resident at once: the taps' reach around the NG*R rows being computed, plus the
+            // NG*R rows published meanwhile
+            g.m_slots = 2 * ngr + (g.a_hi - g.a_lo);
             g.rs = g.m_slots + g.rows - 1;
             if ((g.rs & 1) == 0) ++g.rs;
             if (g.n_groups * g.qp > 1024) continue;
@@ -469,15 +448,21 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         }
     }
     if (!placed) return;
+    // tap table, one row per value of slot(m - a_lo): element offset of every delta tap relative to
+    // this lane's (residue, slot 0) cell.  Padding: the same real tap appended to both signs cancels
+    // (n_plus == n_minus always, because shifting the tap set preserves its size).
     table->clear();
-    auto push_list = [&](const std::vector<Split> &v) {
-        for (int t = 0; t < g.d_pad; ++t) table->push_back((t < (int)v.size() ? v[t] : plus[0]).a - g.a_lo);
-        for (int t = 0; t < g.d_pad; ++t) table->push_back((t < (int)v.size() ? v[t] : plus[0]).b);
-    };
-    // padding: the same real tap appended to both lists cancels (n_plus == n_minus always, because
-    // shifting the tap set preserves its size)
-    push_list(plus);
-    push_list(minus);
+    auto pick = [&](const std::vector<Split> &v, int t) { return t < (int)v.size() ? v[t] : plus[0]; };
+    for (int sl = 0; sl < g.m_slots; ++sl) {
+        for (int sign = 0; sign < 2; ++sign) {
+            for (int t = 0; t < g.d_pad; ++t) {
+                const Split s = pick(sign == 0 ? plus : minus, t);
+                int slot = sl - (s.a - g.a_lo);
+                if (slot < 0) slot += g.m_slots;
+                table->push_back(slot - s.b * g.rs);
+            }
+        }
+    }
     for (size_t k = 0; k < runs.size(); k += 3) {
         table->push_back(runs[k] - g.a_lo);
         table->push_back(runs[k + 1]);
