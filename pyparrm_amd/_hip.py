@@ -311,7 +311,7 @@ def gather_standardise(x, idx, scale, outlier_boundary: float):
 class FitWorkspace:
     """Grow-only device scratch for ``parrm_fit_errors`` (one per stage; avoids per-call mallocs)."""
 
-    MAX_BYTES = 4 << 30
+    MAX_BYTES = 12 << 30
 
     def __init__(self):
         self._buf = None

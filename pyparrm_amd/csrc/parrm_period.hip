@@ -12,6 +12,7 @@
 // No MFMA: FP64 matrix and vector peaks are equal on MI355X (hard part 4).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "parrm_common.h"
@@ -86,21 +87,60 @@ __host__ __device__ inline int kp_for(int bw) {  // padded row count: 4 waves x 
     return K <= 12 ? 12 : (K <= 24 ? 24 : 48);
 }
 
-// part[(((p*nz + zb)*nsplit + s)*(KP+1) + row)*kNCol + col]; row KP holds y'y per column.
-template <int KT>
-__global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t ldy, const int64_t *idx,
-                                                         int n_idx, int n_chans, const double *periods,
-                                                         int bw, int nsplit, double *part) {
-    constexpr int KP = 4 * KT;
-    __shared__ double Wt[kTJ][KP];
+// ---- design matrix ---------------------------------------------------------------------------
+// W[p][k][j] (k-major, j padded to a multiple of kTJ with zeros): 1, sin(a), cos(a), sin(2a), ...
+// with a = (idx_j + 1) * (2*pi / T_p) rounded as the reference rounds it (parrm.py:619).
+//   exact == 0: one sincos(a) per sample, higher harmonics by the angle-addition recurrence
+//               (error ~ k*eps; the reference's own sin(fl(k*a)) carries ~eps*k*a/2 ~ 1e-10 of
+//               argument rounding at a ~ 1e5 rad, so the two agree to that level);
+//   exact == 1: sincos(fl(k*a)) per harmonic, the reference's operation order (:622-623).
+__global__ void __launch_bounds__(256) fit_trig_kernel(const int64_t *idx, int n_idx, int n_pad,
+                                                        const double *periods, int bw, int kpc, int exact,
+                                                        double *W) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (j >= n_pad) return;
+    double *w = W + (static_cast<int64_t>(p) * kpc) * n_pad + j;
+    const int K = 2 * bw + 1;
+    if (j >= n_idx) {
+        for (int k = 0; k < kpc; ++k) w[static_cast<int64_t>(k) * n_pad] = 0.0;
+        return;
+    }
+    const double w0 = 6.283185307179586 / periods[p];             // (2 * np.pi / period)
+    const double ang = static_cast<double>(idx[j] + 1) * w0;      // (indices + 1) * ...
+    w[0] = 1.0;
+    double s1, c1;
+    sincos(ang, &s1, &c1);
+    double sk = s1, ck = c1;
+    for (int k = 1; k <= bw; ++k) {
+        if (exact && k > 1) sincos(static_cast<double>(k) * ang, &sk, &ck);
+        w[static_cast<int64_t>(2 * k - 1) * n_pad] = sk;
+        w[static_cast<int64_t>(2 * k) * n_pad] = ck;
+        const double sn = fma(sk, c1, ck * s1);
+        const double cn = fma(ck, c1, -(sk * s1));
+        sk = sn;
+        ck = cn;
+    }
+    for (int k = K; k < kpc; ++k) w[static_cast<int64_t>(k) * n_pad] = 0.0;
+}
+
+// ---- Gram blocks -----------------------------------------------------------------------------
+// One workgroup = 4 waves x 12 stacked design rows = NCB = 48/KPC candidates (KPC = 12/24/48 padded
+// rows per candidate), all data columns of one 256-channel block plus the 48 stacked W columns
+// (-> each candidate's W'W falls out of the same pass), one slice of the samples.
+// part[(((p*nz + zb)*nsplit + s)*(KPC+1) + row)*kNCol + col]; row KPC holds y'y per column; the
+// Gram matrix of candidate p sits in columns kYCols + (p % NCB)*KPC + [0, K).
+// Tiles of 16 samples go global -> registers (next tile, while the current one is being used) ->
+// LDS; the inner loop is 60 FMAs per 17 LDS reads per lane.
+__global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t ldy, const double *W, int n_pad,
+                                                         int n_idx, int n_chans, int n_periods, int kpc,
+                                                         int nsplit, double *part) {
+    constexpr int KT = 12, KS = 48;
+    __shared__ double Wt[kTJ][KS];
     __shared__ double Yt[kTJ][kNCol];
     const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
-    const int s = blockIdx.x, p = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
-    const int K = 2 * bw + 1;
-    const double w0 = 6.283185307179586 / periods[p];  // (2 * np.pi / period), :619
-
-    for (int it = tid; it < kTJ * KP; it += 256) Wt[it / KP][it % KP] = 0.0;
-    for (int it = tid; it < kTJ * 64; it += 256) Yt[it / 64][kYCols + (it % 64)] = 0.0;
+    const int s = blockIdx.x, pb = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
+    const int ncb = KS / kpc;
 
     double acc[KT][5];
     double yy[5];
@@ -110,38 +150,43 @@ __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) acc[kk][i] = 0.0;
     }
+    for (int it = tid; it < kTJ * 16; it += 256) Yt[it / 16][kYCols + KS + (it % 16)] = 0.0;  // cols 304..319
 
-    const int tiles = (n_idx + kTJ - 1) / kTJ;
+    const int tiles = n_pad / kTJ;
     const int per = (tiles + nsplit - 1) / nsplit;
     const int t_lo = s * per;
     const int t_hi = min(tiles, t_lo + per);
-    __syncthreads();
-    for (int t = t_lo; t < t_hi; ++t) {
+
+    // this thread's share of a tile: 16 Y elements (row j = it/256, column it%256) and 3 W elements
+    // (stacked row r = it/16, sample j = it%16: contiguous in j in the k-major W)
+    double ry[16], rw[3];
+    auto fetch = [&](int t) {
         const int j0 = t * kTJ;
-        for (int it = tid; it < kTJ * (bw + 1); it += 256) {
-            const int j = it % kTJ, k = it / kTJ, jj = j0 + j;
-            if (k == 0) {
-                const double one = jj < n_idx ? 1.0 : 0.0;
-                Wt[j][0] = one;
-                Yt[j][kYCols] = one;
-            } else {
-                double sn = 0.0, cs = 0.0;
-                if (jj < n_idx) {
-                    const double ang = static_cast<double>(idx[jj] + 1) * w0;  // :619
-                    sincos(static_cast<double>(k) * ang, &sn, &cs);            // :622-623
-                }
-                Wt[j][2 * k - 1] = sn;
-                Wt[j][2 * k] = cs;
-                Yt[j][kYCols + 2 * k - 1] = sn;
-                Yt[j][kYCols + 2 * k] = cs;
-            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jj = j0 + i, gc = zb * kYCols + tid;
+            ry[i] = (jj < n_idx && gc < n_chans) ? Y[static_cast<int64_t>(jj) * ldy + gc] : 0.0;
         }
-        for (int it = tid; it < kTJ * kYCols; it += 256) {
-            const int j = it / kYCols, col = it % kYCols, jj = j0 + j;
-            const int gc = zb * kYCols + col;
-            Yt[j][col] = (jj < n_idx && gc < n_chans) ? Y[static_cast<int64_t>(jj) * ldy + gc] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int it = tid + 256 * i, r = it >> 4, j = it & 15;
+            const int pc = pb * ncb + r / kpc;
+            rw[i] = pc < n_periods ? W[(static_cast<int64_t>(pc) * kpc + (r % kpc)) * n_pad + j0 + j] : 0.0;
+        }
+    };
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int t = t_lo; t < t_hi; ++t) {
+        __syncthreads();  // the previous tile is no longer being read
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Yt[i][tid] = ry[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int it = tid + 256 * i, r = it >> 4, j = it & 15;
+            Wt[j][r] = rw[i];
+            Yt[j][kYCols + r] = rw[i];
         }
         __syncthreads();
+        if (t + 1 < t_hi) fetch(t + 1);  // lands during the FMAs below
 #pragma unroll 4
         for (int j = 0; j < kTJ; ++j) {
             double w[KT], y[5];
@@ -156,17 +201,19 @@ __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t
                 for (int kk = 0; kk < KT; ++kk) acc[kk][i] = fma(w[kk], y[i], acc[kk][i]);
             }
         }
-        __syncthreads();
     }
-    (void)K;
-    double *out = part + ((static_cast<int64_t>(p) * nz + zb) * nsplit + s) * (KP + 1) * kNCol;
+    const int r0 = kg * KT;                 // first stacked row of this wave
+    const int pc = pb * ncb + r0 / kpc;     // its candidate
+    if (pc >= n_periods) return;
+    const int k0 = r0 % kpc;
+    double *out = part + ((static_cast<int64_t>(pc) * nz + zb) * nsplit + s) * (kpc + 1) * kNCol;
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) out[(kg * KT + kk) * kNCol + lane + 64 * i] = acc[kk][i];
-    if (kg == 0) {
+        for (int i = 0; i < 5; ++i) out[(k0 + kk) * kNCol + lane + 64 * i] = acc[kk][i];
+    if (k0 == 0) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) out[KP * kNCol + lane + 64 * i] = yy[i];
+        for (int i = 0; i < 5; ++i) out[kpc * kNCol + lane + 64 * i] = yy[i];
     }
 }
 
@@ -186,6 +233,7 @@ __global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int
 // err = mean_c[(y'y - 2 b'R + b'G b)/n + regu . b^2].
 __global__ void __launch_bounds__(256) fit_solve_kernel(const double *red, int n_idx, int n_chans, int bw,
                                                          int KP, int nz, double lambda, double *err) {
+    const int goff = (blockIdx.x % (48 / KP)) * KP;  // this candidate's block of the stacked W columns
     constexpr int KS = 49;   // padded row stride of the K x K matrices
     constexpr int RS = 257;  // padded row stride of the K x 256 right-hand sides
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -204,7 +252,7 @@ __global__ void __launch_bounds__(256) fit_solve_kernel(const double *red, int n
 
     for (int e = tid; e < K * K; e += 256) {
         const int r = e / K, c = e % K;
-        const double g = base[r * kNCol + kYCols + c];
+        const double g = base[r * kNCol + kYCols + goff + c];
         A[r * KS + c] = g;
         G0[r * KS + c] = g;
     }
@@ -310,8 +358,9 @@ __global__ void __launch_bounds__(256) fit_solve_kernel(const double *red, int n
 }
 
 struct FitGeom {
-    int KP, nz, nsplit;
+    int KP, nz, nsplit, n_pad;
     int64_t elems;       // (KP+1)*kNCol
+    size_t w_bytes;      // design matrices
     size_t part_bytes;   // all partial Gram blocks
     size_t red_bytes;    // reduced blocks (0 when nsplit == 1: part is used in place)
 };
@@ -320,12 +369,15 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
     FitGeom g{};
     g.KP = kp_for(bw);
     g.nz = static_cast<int>((n_chans + kYCols - 1) / kYCols);
-    const int64_t tiles = (n_idx + kTJ - 1) / kTJ;
+    g.n_pad = static_cast<int>((n_idx + kTJ - 1) / kTJ * kTJ);
+    const int64_t tiles = g.n_pad / kTJ;
+    const int64_t groups = (n_periods + (48 / g.KP) - 1) / (48 / g.KP);  // workgroups per sample slice
     // aim for >= ~1024 workgroups in flight; never split below 4 tiles per workgroup
-    int64_t want = (1024 + n_periods * g.nz - 1) / (n_periods * g.nz);
+    int64_t want = (1024 + groups * g.nz - 1) / (groups * g.nz);
     want = std::max<int64_t>(1, std::min<int64_t>(want, (tiles + 3) / 4));
     g.nsplit = static_cast<int>(want);
     g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
+    g.w_bytes = static_cast<size_t>(n_periods) * g.KP * g.n_pad * sizeof(double);
     g.part_bytes = static_cast<size_t>(n_periods) * g.nz * g.nsplit * g.elems * sizeof(double);
     g.red_bytes = g.nsplit > 1 ? static_cast<size_t>(n_periods) * g.nz * g.elems * sizeof(double) : 0;
     return g;
@@ -390,7 +442,7 @@ int parrm_gather_standardise(const void *d_x, int x_dtype, int64_t n_chans, int6
 size_t parrm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) {
     if (n_idx <= 0 || n_chans <= 0 || n_periods <= 0 || bw < 0 || bw > kMaxBw) return 0;
     const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw);
-    return g.part_bytes + g.red_bytes;
+    return g.w_bytes + g.part_bytes + g.red_bytes;
 }
 
 int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
@@ -403,22 +455,24 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
                   "fit_errors: bad shape");
     PARRM_REQUIRE(n_periods > 0 && n_periods <= 65535, "fit_errors: 1..65535 periods per call");
     const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw);
-    if (workspace_bytes < g.part_bytes + g.red_bytes) {
-        parrm::set_error("fit_errors: workspace too small (%zu < %zu)", workspace_bytes, g.part_bytes + g.red_bytes);
+    if (workspace_bytes < g.w_bytes + g.part_bytes + g.red_bytes) {
+        parrm::set_error("fit_errors: workspace too small (%zu < %zu)", workspace_bytes,
+                         g.w_bytes + g.part_bytes + g.red_bytes);
         return PARRM_ERR_WORKSPACE;
     }
     PARRM_REQUIRE(g.nz <= 65535, "fit_errors: too many channels");
     hipStream_t s = parrm::as_stream(stream);
-    double *part = static_cast<double *>(d_workspace);
+    double *wmat = static_cast<double *>(d_workspace);
+    double *part = wmat + g.w_bytes / sizeof(double);
     double *red = g.nsplit > 1 ? part + g.part_bytes / sizeof(double) : part;
-    const dim3 grid(g.nsplit, static_cast<unsigned>(n_periods), g.nz);
-    const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans);
-    if (g.KP == 12)
-        hipLaunchKernelGGL(fit_accum_kernel<3>, grid, dim3(256), 0, s, d_y, ldy, d_idx, n, C, d_periods, bw, g.nsplit, part);
-    else if (g.KP == 24)
-        hipLaunchKernelGGL(fit_accum_kernel<6>, grid, dim3(256), 0, s, d_y, ldy, d_idx, n, C, d_periods, bw, g.nsplit, part);
-    else
-        hipLaunchKernelGGL(fit_accum_kernel<12>, grid, dim3(256), 0, s, d_y, ldy, d_idx, n, C, d_periods, bw, g.nsplit, part);
+    const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans), P = static_cast<int>(n_periods);
+    static const int exact_trig = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
+    hipLaunchKernelGGL(fit_trig_kernel, dim3((g.n_pad + 255) / 256, P), dim3(256), 0, s, d_idx, n, g.n_pad, d_periods,
+                       bw, g.KP, exact_trig, wmat);
+    PARRM_HIP_CHECK(hipGetLastError());
+    const int ncb = 48 / g.KP;
+    const dim3 grid(g.nsplit, (P + ncb - 1) / ncb, g.nz);
+    hipLaunchKernelGGL(fit_accum_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit, part);
     PARRM_HIP_CHECK(hipGetLastError());
     if (g.nsplit > 1) {
         const dim3 rgrid(static_cast<unsigned>((g.elems + 255) / 256), static_cast<unsigned>(n_periods * g.nz));

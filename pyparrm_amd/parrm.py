@@ -77,7 +77,8 @@ class PARRM:
     _artefact_freq = None
     _verbose = None
     _period = None
-    _search_samples = None
+    _search_span = None  # (first, last, count) of the sorted search samples
+    _search_samples_array = None
     _assumed_periods = None
     _outlier_boundary = None
     _random_seed = None
@@ -113,6 +114,19 @@ class PARRM:
         if not isinstance(verbose, bool):
             raise TypeError("`verbose` must be a bool.")
         self._verbose = verbose
+
+    @property
+    def _search_samples(self):
+        """Sorted sample indices the period search may use (the reference's attribute of the same
+        name); the default ``arange(N-1)`` is materialised on first access."""
+        if self._search_samples_array is None and self._search_span is not None:
+            self._search_samples_array = np.arange(self._search_span[2])
+        return self._search_samples_array
+
+    @_search_samples.setter
+    def _search_samples(self, value) -> None:
+        self._search_samples_array = value
+        self._search_span = None if value is None else (value[0], value[-1], value.shape[0])
 
     def __repr__(self) -> str:
         return (
@@ -191,13 +205,19 @@ class PARRM:
         if search_samples is not None and not isinstance(search_samples, np.ndarray):
             raise TypeError("`search_samples` must be a NumPy array or None.")
         if search_samples is None:
-            search_samples = np.arange(self._n_samples - 1)
-        elif search_samples.ndim != 1:
-            raise ValueError("`search_samples` must be a 1D array.")
-        search_samples = np.sort(search_samples)
-        if search_samples[0] < 0 or search_samples[-1] >= self._n_samples:
-            raise ValueError("Entries of `search_samples` must lie in the range [0, n_samples).")
-        self._search_samples = search_samples
+            # the reference materialises and sorts arange(N-1) here (parrm.py:225-228) but only ever
+            # reads its first entry, last entry and length (:290,:352,:360,:364); at 10 M samples
+            # that costs more than the whole device search, so the array is built on first access
+            # of `_search_samples` / `settings` instead (same values)
+            self._search_span = (0, self._n_samples - 2, self._n_samples - 1)
+            self._search_samples_array = None
+        else:
+            if search_samples.ndim != 1:
+                raise ValueError("`search_samples` must be a 1D array.")
+            search_samples = np.sort(search_samples)
+            if search_samples[0] < 0 or search_samples[-1] >= self._n_samples:
+                raise ValueError("Entries of `search_samples` must lie in the range [0, n_samples).")
+            self._search_samples = search_samples
 
         if assumed_periods is not None and not isinstance(assumed_periods, (int, float, tuple)):
             raise TypeError("`assumed_periods` must be an int, a float, a tuple, or None.")
@@ -251,7 +271,7 @@ class PARRM:
         rng = np.random.default_rng(self._random_seed)
         estimate = self._assumed_periods
         lengths = np.unique(
-            [int(np.min((self._search_samples.shape[0], n))) for n in _STAGE_LENGTHS]
+            [int(np.min((self._search_span[2], n))) for n in _STAGE_LENGTHS]
         )
         ws = _hip.FitWorkspace()
         trace = []
@@ -292,7 +312,7 @@ class PARRM:
         """Sample indices for one stage (parrm.py:327-374): a contiguous centre block, or -- when
         the block would not exceed ``ignore_portion`` of the recording -- unique random draws
         from the central part.  Kept on the host so the PCG64 draws are the reference's."""
-        first, last = self._search_samples[0], self._search_samples[-1]
+        first, last = self._search_span[0], self._search_span[1]
         centre2 = first + last
         lo = int(np.ceil((centre2 - use_n_samples) / 2))
         hi = int(np.floor((centre2 + use_n_samples) / 2))
