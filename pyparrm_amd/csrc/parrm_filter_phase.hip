@@ -226,7 +226,12 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         // tap offsets for this iteration: one table row, wave-uniform -> scalar loads
         // (fetching the next row early, after the barrier, measured 5 % slower: register pressure)
         int e[2 * DP];
-        const int32_t *trow = p.tab + sl_top * (2 * DP);
+        // readfirstlane: without it hipcc fetched the row with per-lane global loads, whose vmcnt
+        // wait also drained the row prefetch and the previous iteration's stores every iteration
+        // (constant address space: the table is never written by this kernel, which the compiler
+        // cannot prove for a plain global pointer once the kernel has stored to y)
+        typedef const __attribute__((address_space(4))) int32_t *const_i32_ptr;
+        const_i32_ptr trow = (const_i32_ptr)(p.tab) + __builtin_amdgcn_readfirstlane(sl_top) * (2 * DP);
 #pragma unroll
         for (int t = 0; t < 2 * DP; ++t) e[t] = trow[t];
         // 1. request this lane's share of the rows iteration k+2 needs
@@ -428,7 +433,16 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     g.qp = static_cast<int32_t>((q + 2 * g.guard + 63) / 64 * 64);
     g.a_lo = std::min(a_lo, 0);
     g.a_hi = std::max(a_hi, 0);
-    static const int kShapes[][2] = {{2, 4}, {2, 3}, {3, 2}, {2, 2}, {1, 4}, {1, 3}, {1, 2}};
+    int kShapes[8][2] = {{2, 4}, {2, 3}, {3, 2}, {2, 2}, {1, 4}, {1, 3}, {1, 2}, {1, 2}};
+    if (const char *env = getenv("PARRM_PHASE_SHAPE")) {  // tuning knob: "NG,R" tried first
+        int ng = 0, rr = 0;
+        if (sscanf(env, "%d,%d", &ng, &rr) == 2 && ng >= 1 && ng <= 5 && rr >= 2 && rr <= 4) {
+            kShapes[7][0] = kShapes[0][0];
+            kShapes[7][1] = kShapes[0][1];
+            kShapes[0][0] = ng;
+            kShapes[0][1] = rr;
+        }
+    }
     bool placed = false;
     for (int pass = 0; pass < 2 && !placed; ++pass) {
         for (const auto &sh : kShapes) {

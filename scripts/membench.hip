@@ -18,6 +18,8 @@ __global__ void copy_linear(const double2 *x, double2 *y, size_t n) {
 template <int R, int MODE>
 __global__ void __launch_bounds__(1024) copy_stretch(const double *x, double *y, long ld, int q, int qp, int ng,
                                                       long stretch_rows, long n_stretch, long n_samples) {
+    extern __shared__ double lds_pad[];  // only to limit workgroups per CU like the filter kernel
+    if (threadIdx.x == 1025) lds_pad[0] = 0.0;
     const int tid = threadIdx.x;
     const int g = tid / qp, r = tid - g * qp;
     const long c = blockIdx.x / n_stretch, st = blockIdx.x - c * n_stretch;
@@ -84,6 +86,14 @@ int main(int argc, char **argv) {
             snprintf(name, sizeof name, "stretch q=%d rows=%ld R=4 ng=2 barrier", q, rows);
             time(name, [&] { copy_stretch<4, 1><<<C * n_stretch, ng * qp>>>(x, y, N, q, qp, ng, rows, n_stretch, N); });
         }
+    }
+    for (size_t lds : {size_t(0), size_t(40 * 1024), size_t(80 * 1024)}) {
+        const int q = 169, qp = 192, ng = 2;
+        const long rows = 768, n_stretch = (N + rows * q - 1) / (rows * q);
+        char name[128];
+        snprintf(name, sizeof name, "stretch q=169 R=4 ng=2 barrier, LDS %zu KB/block", lds / 1024);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(copy_stretch<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        time(name, [&] { copy_stretch<4, 1><<<C * n_stretch, ng * qp, lds>>>(x, y, N, q, qp, ng, rows, n_stretch, N); });
     }
     {
         const int q = 169, qp = 192, ng = 4;
