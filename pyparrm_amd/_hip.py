@@ -309,18 +309,38 @@ def gather_standardise(x, idx, scale, outlier_boundary: float):
 
 
 class FitWorkspace:
-    """Grow-only device scratch for ``parrm_fit_errors`` (one per stage; avoids per-call mallocs)."""
+    """Grow-only device scratch for ``parrm_fit_errors`` plus pinned staging buffers for the
+    candidate periods / errors (one per stage; avoids per-call mallocs and pageable copies --
+    the Nelder-Mead phase is ~100 small launches whose cost is mostly this plumbing)."""
 
     MAX_BYTES = 12 << 30
 
     def __init__(self):
         self._buf = None
+        self._sizes = {}
+        self._h_per = self._h_err = self._d_per = self._d_err = None
 
     def get(self, nbytes: int, device):
         torch = require_gpu()
         if self._buf is None or self._buf.numel() * 8 < nbytes or self._buf.device != device:
             self._buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
         return self._buf
+
+    def nbytes(self, n_idx: int, n_chans: int, n_per: int, bandwidth: int) -> int:
+        key = (n_idx, n_chans, n_per, bandwidth)
+        if key not in self._sizes:
+            self._sizes[key] = lib().parrm_fit_workspace_bytes(n_idx, n_chans, n_per, bandwidth)
+        return self._sizes[key]
+
+    def staging(self, n_per: int, device):
+        torch = require_gpu()
+        if self._h_per is None or self._h_per.numel() < n_per or self._d_per.device != device:
+            cap = max(64, 2 * n_per)
+            self._h_per = torch.empty(cap, dtype=torch.float64).pin_memory()
+            self._h_err = torch.empty(cap, dtype=torch.float64).pin_memory()
+            self._d_per = torch.empty(cap, dtype=torch.float64, device=device)
+            self._d_err = torch.empty(cap, dtype=torch.float64, device=device)
+        return self._h_per, self._h_err, self._d_per, self._d_err
 
 
 def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, workspace: FitWorkspace | None = None):
@@ -331,28 +351,26 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
     """
     torch = require_gpu()
     L = lib()
-    periods = np.ascontiguousarray(np.asarray(periods, dtype=np.float64).reshape(-1))
+    periods = np.asarray(periods, dtype=np.float64).reshape(-1)
     n_idx, n_chans = y.shape
     n_per = periods.shape[0]
-    out = np.empty(n_per, dtype=np.float64)
     if n_per == 0:
-        return out
+        return np.empty(0, dtype=np.float64)
     ws = workspace or FitWorkspace()
-    # batch so that the scratch stays bounded
-    per_one = L.parrm_fit_workspace_bytes(n_idx, n_chans, 1, bandwidth)
-    if per_one == 0:
+    if ws.nbytes(n_idx, n_chans, 1, bandwidth) == 0:
         raise HipLibraryError("parrm_fit_workspace_bytes rejected the problem shape")
-    batch = n_per
-    while batch > 1 and L.parrm_fit_workspace_bytes(n_idx, n_chans, batch, bandwidth) > FitWorkspace.MAX_BYTES:
+    # batch so that the scratch stays bounded
+    batch = min(n_per, 65535)
+    while batch > 1 and ws.nbytes(n_idx, n_chans, batch, bandwidth) > FitWorkspace.MAX_BYTES:
         batch = (batch + 1) // 2
-    batch = min(batch, 65535)
-    d_per = torch.from_numpy(periods).to(y.device)
-    d_err = torch.empty(n_per, dtype=torch.float64, device=y.device)
+    h_per, h_err, d_per, d_err = ws.staging(n_per, y.device)
+    h_per[:n_per] = torch.from_numpy(periods)
     with torch.cuda.device(y.device):
         stream = _stream_ptr(torch)
+        d_per[:n_per].copy_(h_per[:n_per], non_blocking=True)
         for lo in range(0, n_per, batch):
             cnt = min(batch, n_per - lo)
-            nbytes = L.parrm_fit_workspace_bytes(n_idx, n_chans, cnt, bandwidth)
+            nbytes = ws.nbytes(n_idx, n_chans, cnt, bandwidth)
             buf = ws.get(nbytes, y.device)
             check(
                 L.parrm_fit_errors(
@@ -362,5 +380,6 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
                 ),
                 "parrm_fit_errors",
             )
-    out[:] = d_err.cpu().numpy()
-    return out
+        h_err[:n_per].copy_(d_err[:n_per], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    return h_err[:n_per].numpy().copy()
