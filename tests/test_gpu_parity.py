@@ -384,3 +384,57 @@ def test_config2_properties_64ch_1M():
     yg = plan.apply(a[:2])
     plan.set_kernel(_hip.KERNEL_AUTO)
     assert float((yg - ya[:2]).abs().max()) < 1e-11
+
+
+# ---------------------------------------------------------------------------- input robustness
+def test_facade_input_kinds():
+    """float32 / integer / non-contiguous recordings behave like the reference's dtype rules."""
+    fs, fa = 22000, 130
+    x = synth_recording(3, 40000, fs, fa, seed=9)
+    ref_p = PARRM(x, fs, fa, verbose=False)
+    ref_p.find_period(random_seed=5)
+    ref_p.create_filter()
+    y_ref = ref_p.filter_data()
+    # float32 recording: period close (statistics in float64 of float32 diffs), output float64
+    p32 = PARRM(x.astype(np.float32), fs, fa, verbose=False)
+    p32.find_period(random_seed=5)
+    assert abs(p32.period - ref_p.period) < 1e-6 * ref_p.period
+    p32._period = ref_p.period
+    p32.create_filter()
+    y32 = p32.filter_data()
+    assert y32.dtype == np.float64
+    _assert_filter_close(y32, orc.filter_data_direct(x.astype(np.float32), ref_p.filter))
+    # integer recording: filter_data promotes through float64 (reference: convolve of ints);
+    # find_period raises TypeError like the reference's in-place divide (parrm.py:275)
+    xi = np.round(x * 100).astype(np.int64)
+    pi = PARRM(xi, fs, fa, verbose=False)
+    with pytest.raises(TypeError):
+        pi.find_period()
+    pi._period = ref_p.period
+    pi.create_filter()
+    _assert_filter_close(pi.filter_data(), orc.filter_data_direct(xi.astype(np.float64), ref_p.filter))
+    # Fortran-ordered / sliced view
+    xf = np.asfortranarray(x)
+    pf = PARRM(xf, fs, fa, verbose=False)
+    pf._period = ref_p.period
+    pf.create_filter()
+    assert np.array_equal(pf.filter_data(), y_ref)
+    # other data through the same object, then the cached recording again
+    other = synth_recording(2, 9000, fs, fa, seed=10)
+    _assert_filter_close(ref_p.filter_data(other), orc.filter_data_direct(other, ref_p.filter))
+    assert np.array_equal(ref_p.filter_data(), y_ref)
+
+
+def test_find_period_is_deterministic_and_refindable():
+    x = synth_recording(2, 30000, 22000, 130, seed=12)
+    p = PARRM(x, 22000, 130, verbose=False)
+    p.find_period(random_seed=3)
+    first = p.period
+    p.create_filter()
+    p.filter_data()
+    p.find_period(random_seed=3)  # resets downstream state (parrm.py:196-211)
+    assert p.period == first
+    with pytest.raises(AttributeError):
+        p.filter
+    with pytest.raises(AttributeError):
+        p.filtered_data
