@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     int par = 0;
     const unsigned lds0 = lds_offset(lds_raw) + static_cast<unsigned>(lane_base);
 
+    // running wave-uniform pointers: first requested row / first output row of this wave
+    const TI *xreq = xfast + static_cast<int64_t>(2 * NGR - a_lo + g * R) * q;
+    TO *yout = yrow + (s0 + static_cast<int64_t>(g * R) * q);
     // One iteration = NG*R rows.  `pub` holds the rows requested one iteration ago (published to LDS
     // here), `req` receives the rows of iteration k+2.  The loop below alternates two register sets so
     // that no copy ever touches a register with a load in flight (a copy would force vmcnt(0)).
@@ -234,11 +237,22 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         const_i32_ptr trow = (const_i32_ptr)(p.tab) + __builtin_amdgcn_readfirstlane(sl_top) * (2 * DP);
 #pragma unroll
         for (int t = 0; t < 2 * DP; ++t) e[t] = trow[t];
-        // 1. request this lane's share of the rows iteration k+2 needs
+        // 1. request this lane's share of the rows iteration k+2 needs.  One wave-uniform test
+        // covers the R rows; the interior case is R loads off a running scalar base pointer.
         const int frow = mk + NGR - a_lo + g * R;  // first row this wave publishes now
+        if (more2 && !(p.debug & 4)) {
+            if (frow + NGR >= lrow_lo && frow + NGR + R - 1 <= lrow_hi) {
 #pragma unroll
-        for (int i = 0; i < R; ++i)
-            req[i] = (more2 && filler && !(p.debug & 4)) ? load_row(frow + NGR + i) : TI(0);
+                for (int i = 0; i < R; ++i) req[i] = filler ? (xreq + static_cast<int64_t>(i) * q)[fill_off] : TI(0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) req[i] = filler ? load_row(frow + NGR + i) : TI(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) req[i] = TI(0);
+        }
+        xreq += static_cast<int64_t>(NGR) * q;
         // 2. row sums Delta_i = sum_u d_q(u) xz[(m+i)q + r - u]
         double accp[R], accm[R];
         TI xo[R];
@@ -312,21 +326,26 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         // 5. outputs.  Rows that are interior to the recording and to the stretch take a branch-free
         // path (the test is wave-uniform); edge rows go through emit().
         if (!(p.debug & 2)) {
+            if (m >= erow_lo && m + R - 1 <= erow_hi) {
+                if (active) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                if (m + i >= erow_lo && m + i <= erow_hi) {
-                    if (active) {
-                        double yv = static_cast<double>(xo[i]) - s_row * a.inv_taps;
+                    for (int i = 0; i < R; ++i) {
+                        double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
                         if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
-                        (yrow + (s0 + static_cast<int64_t>(m + i) * q))[static_cast<unsigned>(r)] = static_cast<TO>(yv);
+                        (yout + static_cast<int64_t>(i) * q)[static_cast<unsigned>(r)] = static_cast<TO>(yv);
+                        s_row += delta[i];
                     }
-                } else if (active) {
+                }
+            } else if (active) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
                     const int rel = (m + i) * q + r;
                     if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
+                    s_row += delta[i];
                 }
-                s_row += delta[i];
             }
         }
+        yout += static_cast<int64_t>(NGR) * q;
         par ^= 1;
         sl_top += NGR;
         if (sl_top >= M) sl_top -= M;
