@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--samples", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-only", action="store_true", help="time filter_data alone (config 2 style)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -110,12 +113,17 @@ def main():
     from pyparrm_amd.synth import synth_recording_device
 
     _hip.require_gpu()
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # nccl == RCCL; used for the timing barrier / MAX only
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     n_chans, n_samples = args.chans, args.samples
     x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
