@@ -343,14 +343,49 @@ class PARRM:
     def explore_filter_params(self, time_range=None, time_res=0.01, freq_range=None, freq_res=5.0,
                               n_jobs=1) -> None:
         """Interactive parameter explorer (parrm.py:634-687): GUI, outside this engine's scope
-        (SURVEY.md section 8f-1).  The call-order check is kept."""
+        (SURVEY.md section 8f-1).  The call-order check and the argument contract are kept."""
         self._say("Opening the filter parameter explorer...")
         if self._period is None:
             raise ValueError(_NO_PERIOD)
+        self._check_explorer_inputs(time_range, time_res, freq_range, freq_res, n_jobs)
         raise NotImplementedError(
             "explore_filter_params is a matplotlib GUI of the reference and is not part of the "
             "MI355X hot path; create_filter()/filter_data() can be called repeatedly instead."
         )
+
+    def _check_explorer_inputs(self, time_range, time_res, freq_range, freq_res, n_jobs) -> None:
+        """Argument contract of the explorer (reference: _utils/_plotting.py:101-186), kept so that
+        callers get the reference's errors in the reference's order before the GUI is declined."""
+        max_time = self._n_samples / self._sampling_freq
+        nyquist = self._sampling_freq / 2
+
+        def check_range(value, name, default, bad_bounds, bounds_text):
+            value = default if value is None else value
+            if not isinstance(value, list) or not all(_is_number(entry) for entry in value):
+                raise TypeError(f"`{name}` must be a list of ints or floats.")
+            if len(value) != 2:
+                raise ValueError(f"`{name}` must have a length of 2.")
+            if bad_bounds(value):
+                raise ValueError(f"Entries of `{name}` must lie in the range {bounds_text}.")
+            if value[0] >= value[1]:
+                raise ValueError(f"`{name}[1]` must be > `{name}[0]`.")
+            return value
+
+        time_range = check_range(time_range, "time_range", [0, max_time],
+                                 lambda v: v[0] < 0 or v[1] > max_time, "[0, max. time]")
+        last_sample = np.arange(time_range[0] * self._sampling_freq,
+                                time_range[1] * self._sampling_freq).astype(int)[-1]
+        if not _is_number(time_res):
+            raise TypeError("`time_res` must be an int or a float.")
+        if time_res <= 0 or time_res >= last_sample / self._sampling_freq:
+            raise ValueError("`time_res` must lie in the range (0, max. time).")
+        check_range(freq_range, "freq_range", [1, nyquist],
+                    lambda v: v[0] <= 0 or v[1] > nyquist, "(0, Nyquist frequency]")
+        if not _is_number(freq_res):
+            raise TypeError("`freq_res` must be an int or a float.")
+        if freq_res <= 0 or freq_res > nyquist:
+            raise ValueError("`freq_res` must lie in the range (0, Nyquist frequency].")
+        _checked_n_jobs(n_jobs)
 
     # ------------------------------------------------------------------ create_filter (a9, a10)
     def create_filter(self, filter_half_width=None, omit_n_samples=0, filter_direction="both",

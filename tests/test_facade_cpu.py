@@ -240,3 +240,36 @@ def test_product_never_imports_the_oracle():
     root = pathlib.Path(__file__).resolve().parent.parent / "pyparrm_amd"
     for f in root.rglob("*.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), re.M), f
+
+
+def test_explorer_argument_contract():
+    """reference tests/test_parrm.py:158-180, :239-269 -- errors come before the GUI is declined."""
+    d = _data()
+    p = _with_period(d, 2.023966953751087)
+    for kwargs, exc, msg in [
+        (dict(time_range=0), TypeError, "`time_range` must be a list of ints or floats."),
+        (dict(time_range=[0, "end"]), TypeError, "`time_range` must be a list of ints or floats."),
+        (dict(time_res="all"), TypeError, "`time_res` must be an int or a float."),
+        (dict(freq_range=0), TypeError, "`freq_range` must be a list of ints or floats."),
+        (dict(freq_range=[0, "Nyquist"]), TypeError, "`freq_range` must be a list of ints or floats."),
+        (dict(freq_res=[0]), TypeError, "`freq_res` must be an int or a float."),
+        (dict(n_jobs=1.5), TypeError, "`n_jobs` must be an int."),
+        (dict(time_range=[0, 1, 2]), ValueError, "`time_range` must have a length of 2."),
+        (dict(time_range=[-1, 1]), ValueError, "`time_range` must lie in the range "),
+        (dict(time_range=[0, d.shape[1] / FS + 1]), ValueError, "`time_range` must lie in the range "),
+        (dict(time_range=[1, 0]), ValueError, "`time_range"),
+        (dict(time_res=0), ValueError, "`time_res` must lie in the range "),
+        (dict(time_res=d.shape[1] / FS), ValueError, "`time_res` must lie in the range "),
+        (dict(freq_range=[0, 1, 2]), ValueError, "`freq_range` must have a length of 2."),
+        (dict(freq_range=[-1, 1]), ValueError, "`freq_range` must lie in the range "),
+        (dict(freq_range=[0, FS / 2 + 1]), ValueError, "`freq_range` must lie in the range "),
+        (dict(freq_range=[1, 0]), ValueError, "`freq_range"),
+        (dict(freq_res=0), ValueError, "`freq_res` must lie in the range "),
+        (dict(freq_res=FS / 2 + 1), ValueError, "`freq_res` must lie in the range "),
+        (dict(n_jobs=cpu_count() + 1), ValueError, "`n_jobs` must be <= the number of available CPUs."),
+        (dict(n_jobs=-2), ValueError, "If `n_jobs` is <= 0, it must be -1."),
+    ]:
+        with pytest.raises(exc, match=msg):
+            p.explore_filter_params(**kwargs)
+    with pytest.raises(NotImplementedError):
+        p.explore_filter_params()
