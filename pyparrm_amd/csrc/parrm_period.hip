@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(256) fit_trig_kernel(const int64_t *idx, int n
 // part[(((p*nz + zb)*nsplit + s)*(KPC+1) + row)*kNCol + col]; row KPC holds y'y per column; the
 // Gram matrix of candidate p sits in columns kYCols + (p % NCB)*KPC + [0, K).
 // Tiles of 16 samples go global -> registers (next tile, while the current one is being used) ->
-// LDS; the inner loop is 60 FMAs per 17 LDS reads per lane.
+// LDS; the inner loop is 60 FMAs per 17 LDS reads per lane.  (Feeding the 12 wave-uniform design
+// values through scalar loads + scalar FMA operands instead of LDS was tried: 1.4x slower, the
+// scalar loads could not be prefetched far enough within the SGPR budget.)
 __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t ldy, const double *W, int n_pad,
                                                          int n_idx, int n_chans, int n_periods, int kpc,
                                                          int nsplit, double *part) {
@@ -460,11 +462,9 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
         const int ncol = min(kYCols, n_chans - zb * kYCols);
         double e_c = 0.0;
         if (tid < ncol) {
-            double r0[K], b[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) r0[i] = rz[i * kNCol + tid];
-            // b = P r0 through a per-lane select chain would cost K^2; the permutation is
-            // wave-uniform, so fetch the permuted entry again from global (L2-resident) instead
+            // b = P r: the permutation is wave-uniform, so each entry is fetched from its permuted
+            // row (L2-resident); r itself is re-read for the quadratic form
+            double b[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) b[i] = rz[perm[i] * kNCol + tid];
 #pragma unroll
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
             double t1 = 0.0, t2 = 0.0, reg = 0.0;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                t1 = fma(b[i], r0[i], t1);
+                t1 = fma(b[i], rz[i * kNCol + tid], t1);
                 double g0 = 0.0, g1 = 0.0;
 #pragma unroll
                 for (int j = 0; j + 1 < K; j += 2) {
@@ -530,8 +530,9 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
     g.n_pad = static_cast<int>((n_idx + kTJ - 1) / kTJ * kTJ);
     const int64_t tiles = g.n_pad / kTJ;
     const int64_t groups = (n_periods + (48 / g.KP) - 1) / (48 / g.KP);  // workgroups per sample slice
-    // aim for >= ~1024 workgroups in flight; never split below 4 tiles per workgroup
-    int64_t want = (1024 + groups * g.nz - 1) / (groups * g.nz);
+    // aim for ~2 workgroups per CU (each extra slice costs a 125 KB partial block that
+    // fit_reduce_kernel has to read back); never split below 4 tiles per workgroup
+    int64_t want = (512 + groups * g.nz - 1) / (groups * g.nz);
     want = std::max<int64_t>(1, std::min<int64_t>(want, (tiles + 3) / 4));
     g.nsplit = static_cast<int>(want);
     g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
