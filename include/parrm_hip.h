@@ -151,6 +151,16 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
                      double lambda, double *d_err, void *d_workspace, size_t workspace_bytes,
                      void *stream);
 
+/* Same computation with the candidate periods and the errors in HOST memory: copies the periods
+ * in, runs parrm_fit_errors on `stream`, copies the errors out and synchronises the stream -- one
+ * call per optimiser step (the Nelder-Mead phase of parrm.py:510-517,545-550 is a chain of small,
+ * latency-bound evaluations).  The workspace must hold parrm_fit_workspace_bytes(...) +
+ * 16 * n_periods bytes. */
+int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
+                          int64_t n_chans, const double *h_periods, int64_t n_periods, int bw,
+                          double lambda, double *h_err, void *d_workspace, size_t workspace_bytes,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

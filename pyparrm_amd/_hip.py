@@ -35,6 +35,7 @@ SYMBOLS = (
     "parrm_gather_standardise",
     "parrm_fit_workspace_bytes",
     "parrm_fit_errors",
+    "parrm_fit_errors_host",
 )
 
 
@@ -127,6 +128,8 @@ def lib() -> C.CDLL:
         L.parrm_fit_workspace_bytes.argtypes = [i64, i64, i64, i32]
         L.parrm_fit_errors.restype = i32
         L.parrm_fit_errors.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
+        L.parrm_fit_errors_host.restype = i32
+        L.parrm_fit_errors_host.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
         if L.parrm_hip_abi_version() != 1:
             raise HipLibraryError("libparrm_hip.so has an unexpected ABI version")
         _lib = L
@@ -351,7 +354,7 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
     """
     torch = require_gpu()
     L = lib()
-    periods = np.asarray(periods, dtype=np.float64).reshape(-1)
+    periods = np.ascontiguousarray(np.asarray(periods, dtype=np.float64).reshape(-1))
     n_idx, n_chans = y.shape
     n_per = periods.shape[0]
     if n_per == 0:
@@ -363,6 +366,21 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
     batch = min(n_per, 65535)
     while batch > 1 and ws.nbytes(n_idx, n_chans, batch, bandwidth) > FitWorkspace.MAX_BYTES:
         batch = (batch + 1) // 2
+    if batch == n_per:
+        # one fused call: periods in, kernels, errors out, stream sync (the optimiser's small batches)
+        nbytes = ws.nbytes(n_idx, n_chans, n_per, bandwidth) + 16 * n_per
+        buf = ws.get(nbytes, y.device)
+        out = np.empty(n_per, dtype=np.float64)
+        with torch.cuda.device(y.device):
+            check(
+                L.parrm_fit_errors_host(
+                    y.data_ptr(), y.stride(0), idx.data_ptr(), n_idx, n_chans,
+                    periods.ctypes.data_as(C.c_void_p), n_per, int(bandwidth), float(lambda_),
+                    out.ctypes.data_as(C.c_void_p), buf.data_ptr(), nbytes, _stream_ptr(torch),
+                ),
+                "parrm_fit_errors_host",
+            )
+        return out
     h_per, h_err, d_per, d_err = ws.staging(n_per, y.device)
     h_per[:n_per] = torch.from_numpy(periods)
     with torch.cuda.device(y.device):

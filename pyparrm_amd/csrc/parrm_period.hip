@@ -660,4 +660,28 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
     return PARRM_OK;
 }
 
+int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
+                          const double *h_periods, int64_t n_periods, int bw, double lambda, double *h_err,
+                          void *d_workspace, size_t workspace_bytes, void *stream) {
+    PARRM_REQUIRE(h_periods && h_err && d_workspace, "fit_errors_host: NULL argument");
+    PARRM_REQUIRE(n_periods > 0 && n_periods <= 65535, "fit_errors_host: 1..65535 periods per call");
+    const size_t inner = parrm_fit_workspace_bytes(n_idx, n_chans, n_periods, bw);
+    PARRM_REQUIRE(inner != 0, "fit_errors_host: bad shape");
+    const size_t extra = 2 * static_cast<size_t>(n_periods) * sizeof(double);
+    if (workspace_bytes < inner + extra) {
+        parrm::set_error("fit_errors_host: workspace too small (%zu < %zu)", workspace_bytes, inner + extra);
+        return PARRM_ERR_WORKSPACE;
+    }
+    hipStream_t s = parrm::as_stream(stream);
+    double *d_per = reinterpret_cast<double *>(static_cast<char *>(d_workspace) + inner);
+    double *d_err = d_per + n_periods;
+    PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
+    const int rc = parrm_fit_errors(d_y, ldy, d_idx, n_idx, n_chans, d_per, n_periods, bw, lambda, d_err, d_workspace,
+                                    inner, stream);
+    if (rc != PARRM_OK) return rc;
+    PARRM_HIP_CHECK(hipMemcpyAsync(h_err, d_err, n_periods * sizeof(double), hipMemcpyDeviceToHost, s));
+    PARRM_HIP_CHECK(hipStreamSynchronize(s));
+    return PARRM_OK;
+}
+
 }  // extern "C"
