@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t
                                                          int nsplit, double *part) {
     constexpr int KT = 12, KS = 48;
     __shared__ double Wt[kTJ][KS];
-    __shared__ double Yt[kTJ][kNCol];
+    __shared__ __attribute__((aligned(16))) double Yt[kTJ][kNCol];
     const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
     const int s = blockIdx.x, pb = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
     const int ncb = KS / kpc;
@@ -194,8 +194,16 @@ __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t
             double w[KT], y[5];
 #pragma unroll
             for (int kk = 0; kk < KT; ++kk) w[kk] = Wt[j][kg * KT + kk];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) y[i] = Yt[j][lane + 64 * i];
+            {   // lane l: data columns {2l, 2l+1, 128+2l, 129+2l} as two full-rate ds_read_b128
+                // (contiguous across the wave), stacked-W column 256+l as one ds_read_b64
+                const double2 ya = *reinterpret_cast<const double2 *>(&Yt[j][2 * lane]);
+                const double2 yb = *reinterpret_cast<const double2 *>(&Yt[j][128 + 2 * lane]);
+                y[0] = ya.x;
+                y[1] = ya.y;
+                y[2] = yb.x;
+                y[3] = yb.y;
+                y[4] = Yt[j][kYCols + lane];
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 yy[i] = fma(y[i], y[i], yy[i]);
@@ -209,13 +217,14 @@ __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t
     if (pc >= n_periods) return;
     const int k0 = r0 % kpc;
     double *out = part + ((static_cast<int64_t>(pc) * nz + zb) * nsplit + s) * (kpc + 1) * kNCol;
+    const int col[5] = {2 * lane, 2 * lane + 1, 128 + 2 * lane, 129 + 2 * lane, kYCols + lane};
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) out[(k0 + kk) * kNCol + lane + 64 * i] = acc[kk][i];
+        for (int i = 0; i < 5; ++i) out[(k0 + kk) * kNCol + col[i]] = acc[kk][i];
     if (k0 == 0) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) out[kpc * kNCol + lane + 64 * i] = yy[i];
+        for (int i = 0; i < 5; ++i) out[kpc * kNCol + col[i]] = yy[i];
     }
 }
 
@@ -530,11 +539,22 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
     g.n_pad = static_cast<int>((n_idx + kTJ - 1) / kTJ * kTJ);
     const int64_t tiles = g.n_pad / kTJ;
     const int64_t groups = (n_periods + (48 / g.KP) - 1) / (48 / g.KP);  // workgroups per sample slice
-    // aim for ~2 workgroups per CU (each extra slice costs a 125 KB partial block that
-    // fit_reduce_kernel has to read back); never split below 4 tiles per workgroup
-    int64_t want = (512 + groups * g.nz - 1) / (groups * g.nz);
-    want = std::max<int64_t>(1, std::min<int64_t>(want, (tiles + 3) / 4));
-    g.nsplit = static_cast<int>(want);
+    // Sample slices per candidate group.  512 workgroups are resident at once (2 per CU), so the run
+    // time is ~ceil(workgroups / 512) rounds of (work per workgroup ~ 1/nsplit): pick the nsplit
+    // that minimises rounds/nsplit (e.g. 381 candidates: nsplit 2 -> 762 workgroups = 2 rounds,
+    // nsplit 4 -> 1524 = 3 rounds of half the length).  Each extra slice costs a 125 KB partial block
+    // for fit_reduce_kernel, hence the small per-slice penalty; never below 4 tiles per slice.
+    const int64_t max_split = std::max<int64_t>(1, std::min<int64_t>(64, (tiles + 3) / 4));
+    double best = 1e300;
+    g.nsplit = 1;
+    for (int64_t ns = 1; ns <= max_split; ++ns) {
+        const int64_t rounds = (groups * g.nz * ns + 511) / 512;
+        const double cost = static_cast<double>(rounds) / static_cast<double>(ns) * (1.0 + 0.004 * ns);
+        if (cost < best - 1e-12) {
+            best = cost;
+            g.nsplit = static_cast<int>(ns);
+        }
+    }
     g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
     g.w_bytes = static_cast<size_t>(n_periods) * g.KP * g.n_pad * sizeof(double);
     g.part_bytes = static_cast<size_t>(n_periods) * g.nz * g.nsplit * g.elems * sizeof(double);
