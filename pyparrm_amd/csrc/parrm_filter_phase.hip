@@ -274,7 +274,11 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             auto accumulate = [&](int j, TI (&b)[R]) {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    if (j & 1)
+                    if (j == 0)
+                        accp[i] = static_cast<double>(b[i]);  // first +1 tap: no zero-init needed
+                    else if (j == 1)
+                        accm[i] = static_cast<double>(b[i]);  // first -1 tap
+                    else if (j & 1)
                         accm[i] += static_cast<double>(b[i]);
                     else
                         accp[i] += static_cast<double>(b[i]);
@@ -317,10 +321,13 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         if (!(p.debug & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // 4. chain the groups: S at this wave's first row, and S at the next iteration's base row
         double s_row = S, s_all = 0.0;
-        for (int gg = 0; gg < NG; ++gg) {
-            const double tg = xchg[(par * NG + gg) * QP + r];
-            if (gg < g) s_row += tg;
-            s_all += tg;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {  // NG <= 4; fixed trip count keeps this straight-line
+            if (gg < NG) {
+                const double tg = xchg[(par * NG + gg) * QP + r];
+                s_row += gg < g ? tg : 0.0;
+                s_all += tg;
+            }
         }
         S += s_all;
         // 5. outputs.  Rows that are interior to the recording and to the stretch take a branch-free
