@@ -30,6 +30,7 @@ namespace parrm_filter {
 
 namespace {
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kMaxGuard = 24;
 constexpr size_t kLdsTwoBlocks = 80 * 1024;   // 2 workgroups per CU
 constexpr size_t kLdsOneBlock = 160 * 1024;
@@ -142,7 +143,8 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     // Cell (rho, row) holds sample s0 + row*q + rho for every rho in [-B, q+B): the B-wide halos are
     // ordinary columns owned by the otherwise idle lanes of the last wave.  slot(row) = (row+a_hi) mod M.
     const int fill_base = (rho + B) * RS * kEl;                  // byte offset of (rho, slot 0)
-    const int lane_base = ((active ? r : 0) + B) * RS * kEl;     // byte offset of (r, slot 0)
+    // (idle lanes mirror the last residue: same address as a lane of their own half -> broadcast, no bank conflict)
+    const int lane_base = ((active ? r : q - 1) + B) * RS * kEl;  // byte offset of (r, slot 0)
     // Rows whose whole span (halos included) is addressable take a wave-uniform fast path: scalar
     // base pointer + per-lane unsigned offset (no per-lane bounds tests).  Computed once per stretch.
     auto floor_div = [](int64_t x, int64_t d) -> int64_t { return x >= 0 ? x / d : -((-x + d - 1) / d); };
@@ -184,6 +186,8 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             }
         }
     }
+    // the exchange cells start at zero (the skewed interior loop reads the previous iteration's cell on entry)
+    for (int k = tid; k < 2 * NG * QP; k += blockDim.x) xchg[k] = 0.0;
     // rows of iteration 1 are requested now (published during iteration 0)
     TI pre_a[R];
 #pragma unroll
@@ -215,54 +219,38 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     int sl_fill = (NGR - a_lo + g * R + a_hi) % M;  // slot of the first row this wave publishes
     int par = 0;
     const unsigned lds0 = lds_offset(lds_raw) + static_cast<unsigned>(lane_base);
+    auto advance_slots = [&]() {
+        par ^= 1;
+        sl_top += NGR;
+        if (sl_top >= M) sl_top -= M;
+        sl_own += NGR;
+        if (sl_own >= M) sl_own -= M;
+        sl_fill += NGR;
+        if (sl_fill >= M) sl_fill -= M;
+    };
 
-    // running wave-uniform pointers: first requested row / first output row of this wave
-    const TI *xreq = xfast + static_cast<int64_t>(2 * NGR - a_lo + g * R) * q;
-    TO *yout = yrow + (s0 + static_cast<int64_t>(g * R) * q);
-    // One iteration = NG*R rows.  `pub` holds the rows requested one iteration ago (published to LDS
-    // here), `req` receives the rows of iteration k+2.  The loop below alternates two register sets so
-    // that no copy ever touches a register with a load in flight (a copy would force vmcnt(0)).
-    auto iteration = [&](const int mk, TI (&pub)[R], TI (&req)[R]) {
-        const int m = mk + g * R;
-        const bool more = mk + NGR < rows_total;
-        const bool more2 = mk + 2 * NGR < rows_total;
-        // tap offsets for this iteration: one table row, wave-uniform -> scalar loads
-        // (fetching the next row early, after the barrier, measured 5 % slower: register pressure)
-        int e[2 * DP];
-        // readfirstlane: without it hipcc fetched the row with per-lane global loads, whose vmcnt
-        // wait also drained the row prefetch and the previous iteration's stores every iteration
-        // (constant address space: the table is never written by this kernel, which the compiler
-        // cannot prove for a plain global pointer once the kernel has stored to y)
-        typedef const __attribute__((address_space(4))) int32_t *const_i32_ptr;
-        const_i32_ptr trow = (const_i32_ptr)(p.tab) + __builtin_amdgcn_readfirstlane(sl_top) * (2 * DP);
+    // Tap offsets for one iteration: one table row, wave-uniform -> scalar loads.  Constant address
+    // space + readfirstlane: the table is never written by this kernel, which the compiler cannot
+    // prove for a plain global pointer once the kernel has stored to y -- it then fetches the row
+    // with per-lane global loads whose vmcnt wait also drains the row prefetch and the previous
+    // iteration's stores every iteration.
+    typedef const __attribute__((address_space(4))) int32_t *const_i32_ptr;
+    // 2. row sums Delta_i = sum_u d_q(u) xz[(m+i)q + r - u], and this lane's own samples of the rows
+    int e[2 * DP];
+    auto fetch_table = [&](int sl) {
+        const_i32_ptr trow = (const_i32_ptr)(p.tab) + __builtin_amdgcn_readfirstlane(sl) * (2 * DP);
 #pragma unroll
         for (int t = 0; t < 2 * DP; ++t) e[t] = trow[t];
-        // 1. request this lane's share of the rows iteration k+2 needs.  One wave-uniform test
-        // covers the R rows; the interior case is R loads off a running scalar base pointer.
-        const int frow = mk + NGR - a_lo + g * R;  // first row this wave publishes now
-        if (more2 && !(p.debug & 4)) {
-            if (frow + NGR >= lrow_lo && frow + NGR + R - 1 <= lrow_hi) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) req[i] = filler ? (xreq + static_cast<int64_t>(i) * q)[fill_off] : TI(0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < R; ++i) req[i] = filler ? load_row(frow + NGR + i) : TI(0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < R; ++i) req[i] = TI(0);
-        }
-        xreq += static_cast<int64_t>(NGR) * q;
-        // 2. row sums Delta_i = sum_u d_q(u) xz[(m+i)q + r - u]
+    };
+    auto tap_sums = [&](double (&delta)[R], const bool skip_taps) {
+        fetch_table(sl_top);
         double accp[R], accm[R];
-        TI xo[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             accp[i] = 0.0;
             accm[i] = 0.0;
-            xo[i] = *reinterpret_cast<const TI *>(lds_raw + lane_base + (sl_own + i) * kEl);
         }
-        if (!(p.debug & 1)) {
+        if (!skip_taps) {
             // 2*DP row-sets, plus and minus interleaved; a ring of four register sets keeps three
             // row-sets (3*R reads) in flight behind the one being accumulated
             constexpr int NS = 2 * DP;
@@ -299,13 +287,76 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             accumulate(NS - 2, v[(NS - 2) & 3]);
             accumulate(NS - 1, v[(NS - 1) & 3]);
         }
+#pragma unroll
+        for (int i = 0; i < R; ++i) delta[i] = accp[i] - accm[i];
+    };
+    // this lane's own samples of the rows (needed only for the outputs: requested after the tap loop
+    // so that nothing has to drain in front of it)
+    auto own_samples = [&](TI (&xo)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) xo[i] = *reinterpret_cast<const TI *>(lds_raw + lane_base + (sl_own + i) * kEl);
+    };
+    // 4. chain the groups after the barrier: returns S at this wave's first row and moves S to the
+    // next iteration's base row
+    auto chain = [&]() -> double {
+        const double *xc = xchg + (par * NG) * QP + r;
+        double t[4];
+        t[0] = xc[0];
+        if (NG > 1) t[1] = xc[QP];
+        if (NG > 2) t[2] = xc[2 * QP];
+        if (NG > 3) t[3] = xc[3 * QP];
+        double s_row = S, s_all = t[0];
+        if (NG > 1) {
+            if (g > 0) s_row += t[0];
+            s_all += t[1];
+        }
+        if (NG > 2) {
+            if (g > 1) s_row += t[1];
+            s_all += t[2];
+        }
+        if (NG > 3) {
+            if (g > 2) s_row += t[2];
+            s_all += t[3];
+        }
+        S += s_all;
+        return s_row;
+    };
+    // LDS-only barrier: a plain __syncthreads() also waits vmcnt(0), i.e. for the global loads
+    // requested above and for the previous iteration's output stores, once per iteration
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // One iteration = NG*R rows.  `pub` holds the rows requested one iteration ago (published to LDS
+    // here), `req` receives the rows of iteration k+2.  The loops below alternate two register sets so
+    // that no copy ever touches a register with a load in flight (a copy would force vmcnt(0)).
+    //
+    // General form: any iteration of the stretch (recording edges, stretch tail, ablation flags).
+    auto iteration = [&](const int mk, TI (&pub)[R], TI (&req)[R]) {
+        const int m = mk + g * R;
+        const bool more = mk + NGR < rows_total;
+        const bool more2 = mk + 2 * NGR < rows_total;
+        // 1. request this lane's share of the rows iteration k+2 needs.  One wave-uniform test
+        // covers the R rows; the interior case is R loads off a wave-uniform base pointer.
+        const int frow = mk + NGR - a_lo + g * R;  // first row this wave publishes now
+        if (more2 && !(p.debug & 4)) {
+            if (frow + NGR >= lrow_lo && frow + NGR + R - 1 <= lrow_hi) {
+                const TI *xreq = xfast + static_cast<int64_t>(frow + NGR) * q;
+#pragma unroll
+                for (int i = 0; i < R; ++i) req[i] = filler ? (xreq + static_cast<int64_t>(i) * q)[fill_off] : TI(0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) req[i] = filler ? load_row(frow + NGR + i) : TI(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) req[i] = TI(0);
+        }
+        TI xo[R];
         double delta[R];
+        tap_sums(delta, (p.debug & 1) != 0);
+        own_samples(xo);
         double tot = 0.0;
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            delta[i] = accp[i] - accm[i];
-            tot += delta[i];
-        }
+        for (int i = 0; i < R; ++i) tot += delta[i];
         xchg[(par * NG + g) * QP + r] = tot;
         // 3. publish the rows requested one iteration ago (their slots alias rows older than mk - a_hi)
         if (more && filler && !(p.debug & 4)) {
@@ -316,25 +367,14 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
                 store_row(sl, pub[i]);
             }
         }
-        // LDS-only barrier: a plain __syncthreads() also waits vmcnt(0), i.e. for the global loads
-        // requested above and for the previous iteration's output stores, once per iteration
-        if (!(p.debug & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // 4. chain the groups: S at this wave's first row, and S at the next iteration's base row
-        double s_row = S, s_all = 0.0;
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {  // NG <= 4; fixed trip count keeps this straight-line
-            if (gg < NG) {
-                const double tg = xchg[(par * NG + gg) * QP + r];
-                s_row += gg < g ? tg : 0.0;
-                s_all += tg;
-            }
-        }
-        S += s_all;
+        if (!(p.debug & 8)) lds_barrier();
+        double s_row = chain();
         // 5. outputs.  Rows that are interior to the recording and to the stretch take a branch-free
         // path (the test is wave-uniform); edge rows go through emit().
         if (!(p.debug & 2)) {
             if (m >= erow_lo && m + R - 1 <= erow_hi) {
                 if (active) {
+                    TO *yout = yrow + (s0 + static_cast<int64_t>(m) * q);
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
@@ -352,19 +392,210 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
                 }
             }
         }
-        yout += static_cast<int64_t>(NGR) * q;
-        par ^= 1;
-        sl_top += NGR;
-        if (sl_top >= M) sl_top -= M;
-        sl_own += NGR;
-        if (sl_own >= M) sl_own -= M;
-        sl_fill += NGR;
-        if (sl_fill >= M) sl_fill -= M;
+        advance_slots();
     };
+
+    // Interior form: every row requested, published and written by the NEXT TWO iterations of every
+    // wave of the workgroup lies inside the recording and the stretch, and byte offsets fit 31 bits.
+    // Rows go through buffer descriptors: wave-uniform scalar offsets carry the row position, one
+    // constant per-lane offset carries the column, and lanes without a column get an out-of-range
+    // offset (the range check returns 0 for their loads and drops their stores) -- no per-lane
+    // address arithmetic, no bounds tests, no exec juggling.
+    constexpr unsigned kNoColumn = 0x80000000u;
+    const int64_t xbytes = a.buf_len * kEl, ybytes = a.out_len * static_cast<int64_t>(sizeof(TO));
+    const bool fast_ok = !(p.debug & 31) && xbytes < 0x7fffff00LL && ybytes < 0x7fffff00LL;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TI *>(xrow), 0, static_cast<int>(fast_ok ? xbytes : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+        yrow + a.out_first, 0, static_cast<int>(fast_ok ? ybytes : 0), 0x00020000);
+    const unsigned voff_x = filler ? fill_off * kEl : kNoColumn;
+    const unsigned voff_y = active ? static_cast<unsigned>(r) * static_cast<unsigned>(sizeof(TO)) : kNoColumn;
+    const unsigned qx = static_cast<unsigned>(q) * kEl, qy = static_cast<unsigned>(q) * static_cast<unsigned>(sizeof(TO));
+    // first base row mk of an interior PAIR of iterations: mk in [pair_lo, pair_hi]
+    const int pair_lo = std::max(erow_lo, lrow_lo - 2 * NGR + a_lo);
+    const int pair_hi = std::min(std::min(rows_total - 3 * NGR - 1, lrow_hi - 4 * NGR + a_lo + 1), erow_hi - 2 * NGR + 1);
+    unsigned soff_x = 0, soff_y = 0;  // set on entry to the interior loop
+    auto fast_iteration = [&](TI (&pub)[R], TI (&req)[R]) {
+        // 1. request rows (iteration k+2)
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if constexpr (kEl == 8) {
+                req[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, voff_x, soff_x + i * qx, 0));
+            } else {
+                req[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, voff_x, soff_x + i * qx, 0));
+            }
+        }
+        soff_x += static_cast<unsigned>(NGR) * qx;
+        TI xo[R];
+        double delta[R];
+        tap_sums(delta, false);
+        own_samples(xo);
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) tot += delta[i];
+        xchg[(par * NG + g) * QP + r] = tot;
+        // 3. publish
+        if (filler) {
+            if (sl_fill >= R - 1 && sl_fill + R <= M) {  // no wrap, no mirrored head: R adjacent cells
+                TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl_fill * kEl);
+#pragma unroll
+                for (int i = 0; i < R; ++i) cell[i] = pub[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    int sl = sl_fill + i;
+                    if (sl >= M) sl -= M;
+                    store_row(sl, pub[i]);
+                }
+            }
+        }
+        lds_barrier();
+        double s_row = chain();
+        // 5. outputs
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
+            if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+            const TO yo = static_cast<TO>(yv);
+            if constexpr (sizeof(TO) == 8) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+            }
+            s_row += delta[i];
+        }
+        soff_y += static_cast<unsigned>(NGR) * qy;
+        advance_slots();
+    };
+
+    // Interior form for two row groups, SKEWED by half an iteration: while group 0 streams its taps
+    // from LDS (array-bound), group 1 does everything else for its previous rows (outputs, publish,
+    // requests: issue-bound), then they swap -- two barriers per iteration.  Waves in lock-step
+    // otherwise compete for the same issue port / the LDS array in every phase and the two kinds
+    // of time add up.  Group 0's outputs of iteration k need S_k only; group 1's need S_k plus
+    // group 0's total of iteration k, which was exchanged half an iteration earlier.
+    //   half-step A(k): g0 taps(k)          | g1 rest(k-1)
+    //   half-step B(k): g0 rest(k)          | g1 taps(k)
+    // One register set carries the rows: rest(k) publishes the rows of iteration k+1 and then
+    // requests the rows of k+2 into the same registers.
+    const int one_lo = pair_lo;
+    const int one_hi = std::min(std::min(rows_total - 2 * NGR - 1, lrow_hi - 3 * NGR + a_lo + 1), erow_hi - NGR + 1);
+    auto skew_taps = [&](double (&delta)[R], double &tot) {
+        tap_sums(delta, false);
+        tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) tot += delta[i];
+        xchg[(par * 2 + g) * QP + r] = tot;
+    };
+    auto skew_rest = [&](TI (&rows)[R], const double (&delta)[R], const double tot, double &own_prev) {
+        // the other group's total: g0 needs tot_1(k-1), g1 needs tot_0(k)
+        const double other = xchg[(g == 0 ? (par ^ 1) * 2 + 1 : par * 2) * QP + r];
+        TI xo[R];
+        own_samples(xo);
+        if (filler) {
+            if (sl_fill >= R - 1 && sl_fill + R <= M) {  // no wrap, no mirrored head: R adjacent cells
+                TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl_fill * kEl);
+#pragma unroll
+                for (int i = 0; i < R; ++i) cell[i] = rows[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    int sl = sl_fill + i;
+                    if (sl >= M) sl -= M;
+                    store_row(sl, rows[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if constexpr (kEl == 8) {
+                rows[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, voff_x, soff_x + i * qx, 0));
+            } else {
+                rows[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, voff_x, soff_x + i * qx, 0));
+            }
+        }
+        soff_x += static_cast<unsigned>(NGR) * qx;
+        double s_row;
+        if (g == 0) {
+            S += own_prev + other;
+            s_row = S;
+            own_prev = tot;
+        } else {
+            s_row = S + other;
+            S = s_row + tot;
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
+            if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+            const TO yo = static_cast<TO>(yv);
+            if constexpr (sizeof(TO) == 8) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+            }
+            s_row += delta[i];
+        }
+        soff_y += static_cast<unsigned>(NGR) * qy;
+        advance_slots();
+    };
+
     TI pre_b[R];
-    for (int mk = 0; mk < rows_total; mk += 2 * NGR) {
-        iteration(mk, pre_a, pre_b);
-        if (mk + NGR < rows_total) iteration(mk + NGR, pre_b, pre_a);
+    int mk = 0;
+    while (mk < rows_total) {
+        if (fast_ok && NG == 2 && mk >= one_lo && mk + 2 * NGR <= one_hi) {
+            const int n_it = ((one_hi - NGR - mk) / NGR + 1) & ~1;  // even; requests reach one iteration further
+            soff_x = static_cast<unsigned>((s0 - B - a.buf_first + static_cast<int64_t>(mk + 2 * NGR - a_lo + g * R) * q) * kEl);
+            // rows of iteration k0+2 (the general form would request them during k0)
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if constexpr (kEl == 8) {
+                    pre_b[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, voff_x, soff_x + i * qx, 0));
+                } else {
+                    pre_b[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, voff_x, soff_x + i * qx, 0));
+                }
+            }
+            soff_x += static_cast<unsigned>(NGR) * qx;
+            soff_y = static_cast<unsigned>((s0 - a.out_first + static_cast<int64_t>(mk + g * R) * q) *
+                                           static_cast<int64_t>(sizeof(TO)));
+            // S is already S_k on entry: cancel group 0's first update with the cell it will read
+            double own_prev = 0.0;
+            if (g == 0)
+                own_prev = -xchg[((par ^ 1) * 2 + 1) * QP + r];
+            else
+                lds_barrier();  // group 1 idles through A(k0)
+            double delta[R], tot;
+#pragma nounroll
+            for (int it = 0; it < n_it; it += 2) {
+                skew_taps(delta, tot);
+                lds_barrier();
+                skew_rest(pre_a, delta, tot, own_prev);
+                lds_barrier();
+                skew_taps(delta, tot);
+                lds_barrier();
+                skew_rest(pre_b, delta, tot, own_prev);
+                lds_barrier();
+            }
+            if (g == 0) {  // group 1 is doing rest(k_last); bring S to the next base row
+                S += own_prev + xchg[((par ^ 1) * 2 + 1) * QP + r];
+                lds_barrier();
+            }
+            mk += n_it * NGR;
+        } else if (fast_ok && mk >= pair_lo && mk <= pair_hi) {
+            // sample of (row, column 0 of the fill lanes) = s0 - B + row*q; of an output row = s0 + row*q
+            soff_x = static_cast<unsigned>((s0 - B - a.buf_first + static_cast<int64_t>(mk + 2 * NGR - a_lo + g * R) * q) * kEl);
+            soff_y = static_cast<unsigned>((s0 - a.out_first + static_cast<int64_t>(mk + g * R) * q) *
+                                           static_cast<int64_t>(sizeof(TO)));
+            do {
+                fast_iteration(pre_a, pre_b);
+                fast_iteration(pre_b, pre_a);
+                mk += 2 * NGR;
+            } while (mk <= pair_hi);
+        } else {
+            iteration(mk, pre_a, pre_b);
+            if (mk + NGR < rows_total) iteration(mk + NGR, pre_b, pre_a);
+            mk += 2 * NGR;
+        }
     }
 }
 
@@ -459,7 +690,10 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     g.qp = static_cast<int32_t>((q + 2 * g.guard + 63) / 64 * 64);
     g.a_lo = std::min(a_lo, 0);
     g.a_hi = std::max(a_hi, 0);
-    int kShapes[8][2] = {{2, 4}, {2, 3}, {3, 2}, {2, 2}, {1, 4}, {1, 3}, {1, 2}, {1, 2}};
+    // (groups, rows per thread), best first.  Measured on 256 x 10M f64, q = 169: (4,2) 10.2 ms,
+    // (2,3) 10.3, (2,4) 10.4, (2,2) 11.2, (3,2) 11.5, (3,3) 11.9 -- 24 waves per CU (two 12-wave
+    // workgroups, three waves per SIMD each) hide more latency than the extra instructions of R = 2 cost.
+    int kShapes[8][2] = {{4, 2}, {2, 4}, {2, 3}, {2, 2}, {3, 2}, {1, 4}, {1, 3}, {1, 2}};
     if (const char *env = getenv("PARRM_PHASE_SHAPE")) {  // tuning knob: "NG,R" tried first
         int ng = 0, rr = 0;
         if (sscanf(env, "%d,%d", &ng, &rr) == 2 && ng >= 1 && ng <= 5 && rr >= 2 && rr <= 4) {

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root: SQ/LDS counters of the filter kernel, one
+# --pmc pass per group (rocprofv3 PMC slots are limited; never combined with sys/hip traces).
+set -e -o pipefail
+TAG=${1:-sq}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$ROOT/scripts/profile_filter.py" --kernel phase --reps 1 > "$OUT/g$i.log" 2>&1 || echo "group $i failed"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:60]
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+with open(out + "/summary.txt", "w") as fh:
+    for k, d in tot.items():
+        if "filter" not in k: continue
+        fh.write(k + "\n")
+        for c, v in sorted(d.items()): fh.write(f"  {c} {v:.6g}\n")
+print(open(out + "/summary.txt").read())
+PY
