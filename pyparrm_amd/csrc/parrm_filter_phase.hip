@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "parrm_filter_internal.h"
 
@@ -108,6 +109,30 @@ __device__ inline void tap_rows(unsigned ad, TI (&v)[R]) {
     }
 }
 
+// R == 2: one unit = the +1 and the -1 row-set of one delta pair (4 reads, two addresses), so that
+// one counted wait covers four reads.  WAIT = 4: on return the previous unit is back.
+template <typename TI, int WAIT>
+__device__ inline void tap_pair(unsigned ad_p, unsigned ad_m, TI (&v)[4]) {
+    static_assert(WAIT == -1 || WAIT == 4, "wait count");
+    if constexpr (sizeof(TI) == 8) {
+        if constexpr (WAIT == 4)
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\t"
+                         "s_waitcnt lgkmcnt(4)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad_p), "v"(ad_m));
+        else
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad_p), "v"(ad_m));
+    } else {
+        if constexpr (WAIT == 4)
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %5\n\tds_read_b32 %3, %5 offset:4\n\t"
+                         "s_waitcnt lgkmcnt(4)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad_p), "v"(ad_m));
+        else
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %5\n\tds_read_b32 %3, %5 offset:4"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ad_p), "v"(ad_m));
+    }
+}
+
 template <typename TI, typename TO, int DP, int R>
 __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseGeom p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -186,8 +211,6 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             }
         }
     }
-    // the exchange cells start at zero (the skewed interior loop reads the previous iteration's cell on entry)
-    for (int k = tid; k < 2 * NG * QP; k += blockDim.x) xchg[k] = 0.0;
     // rows of iteration 1 are requested now (published during iteration 0)
     TI pre_a[R];
 #pragma unroll
@@ -250,7 +273,39 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             accp[i] = 0.0;
             accm[i] = 0.0;
         }
-        if (!skip_taps) {
+        if (skip_taps) {
+        } else if constexpr (R == 2) {
+            // DP units of (+1 row-set, -1 row-set); two register sets: one unit in flight behind the
+            // one being accumulated, one counted wait per four reads
+            TI v[2][4];
+            auto issue = [&](int u, TI (&b)[4], auto wait) {
+                tap_pair<TI, decltype(wait)::value>(lds0 + (static_cast<unsigned>(e[u]) << kElLog2),
+                                                    lds0 + (static_cast<unsigned>(e[DP + u]) << kElLog2), b);
+            };
+            auto accumulate = [&](int u, TI (&b)[4]) {
+                if (u == 0) {
+                    accp[0] = static_cast<double>(b[0]);
+                    accp[1] = static_cast<double>(b[1]);
+                    accm[0] = static_cast<double>(b[2]);
+                    accm[1] = static_cast<double>(b[3]);
+                } else {
+                    accp[0] += static_cast<double>(b[0]);
+                    accp[1] += static_cast<double>(b[1]);
+                    accm[0] += static_cast<double>(b[2]);
+                    accm[1] += static_cast<double>(b[3]);
+                }
+            };
+            issue(0, v[0], std::integral_constant<int, -1>{});
+#pragma unroll
+            for (int u = 1; u < DP; ++u) {
+                issue(u, v[u & 1], std::integral_constant<int, 4>{});  // returns once unit u-1 is back
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(u - 1, v[(u - 1) & 1]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(DP - 1, v[(DP - 1) & 1]);
+        } else {
             // 2*DP row-sets, plus and minus interleaved; a ring of four register sets keeps three
             // row-sets (3*R reads) in flight behind the one being accumulated
             constexpr int NS = 2 * DP;
@@ -298,25 +353,22 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     };
     // 4. chain the groups after the barrier: returns S at this wave's first row and moves S to the
     // next iteration's base row
+    // (weights instead of selects: fma(1, t, s) rounds like s + t and fma(0, t, s) is s)
+    const double w0 = g > 0 ? 1.0 : 0.0, w1 = g > 1 ? 1.0 : 0.0, w2 = g > 2 ? 1.0 : 0.0;
     auto chain = [&]() -> double {
         const double *xc = xchg + (par * NG) * QP + r;
-        double t[4];
-        t[0] = xc[0];
-        if (NG > 1) t[1] = xc[QP];
-        if (NG > 2) t[2] = xc[2 * QP];
-        if (NG > 3) t[3] = xc[3 * QP];
-        double s_row = S, s_all = t[0];
+        double s_row = S, s_all = xc[0];
         if (NG > 1) {
-            if (g > 0) s_row += t[0];
-            s_all += t[1];
+            s_row = fma(w0, s_all, s_row);
+            s_all += xc[QP];
         }
         if (NG > 2) {
-            if (g > 1) s_row += t[1];
-            s_all += t[2];
+            s_row = fma(w1, xc[QP], s_row);
+            s_all += xc[2 * QP];
         }
         if (NG > 3) {
-            if (g > 2) s_row += t[2];
-            s_all += t[3];
+            s_row = fma(w2, xc[2 * QP], s_row);
+            s_all += xc[3 * QP];
         }
         S += s_all;
         return s_row;
@@ -468,120 +520,10 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         advance_slots();
     };
 
-    // Interior form for two row groups, SKEWED by half an iteration: while group 0 streams its taps
-    // from LDS (array-bound), group 1 does everything else for its previous rows (outputs, publish,
-    // requests: issue-bound), then they swap -- two barriers per iteration.  Waves in lock-step
-    // otherwise compete for the same issue port / the LDS array in every phase and the two kinds
-    // of time add up.  Group 0's outputs of iteration k need S_k only; group 1's need S_k plus
-    // group 0's total of iteration k, which was exchanged half an iteration earlier.
-    //   half-step A(k): g0 taps(k)          | g1 rest(k-1)
-    //   half-step B(k): g0 rest(k)          | g1 taps(k)
-    // One register set carries the rows: rest(k) publishes the rows of iteration k+1 and then
-    // requests the rows of k+2 into the same registers.
-    const int one_lo = pair_lo;
-    const int one_hi = std::min(std::min(rows_total - 2 * NGR - 1, lrow_hi - 3 * NGR + a_lo + 1), erow_hi - NGR + 1);
-    auto skew_taps = [&](double (&delta)[R], double &tot) {
-        tap_sums(delta, false);
-        tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) tot += delta[i];
-        xchg[(par * 2 + g) * QP + r] = tot;
-    };
-    auto skew_rest = [&](TI (&rows)[R], const double (&delta)[R], const double tot, double &own_prev) {
-        // the other group's total: g0 needs tot_1(k-1), g1 needs tot_0(k)
-        const double other = xchg[(g == 0 ? (par ^ 1) * 2 + 1 : par * 2) * QP + r];
-        TI xo[R];
-        own_samples(xo);
-        if (filler) {
-            if (sl_fill >= R - 1 && sl_fill + R <= M) {  // no wrap, no mirrored head: R adjacent cells
-                TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl_fill * kEl);
-#pragma unroll
-                for (int i = 0; i < R; ++i) cell[i] = rows[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    int sl = sl_fill + i;
-                    if (sl >= M) sl -= M;
-                    store_row(sl, rows[i]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            if constexpr (kEl == 8) {
-                rows[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, voff_x, soff_x + i * qx, 0));
-            } else {
-                rows[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, voff_x, soff_x + i * qx, 0));
-            }
-        }
-        soff_x += static_cast<unsigned>(NGR) * qx;
-        double s_row;
-        if (g == 0) {
-            S += own_prev + other;
-            s_row = S;
-            own_prev = tot;
-        } else {
-            s_row = S + other;
-            S = s_row + tot;
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-            if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
-            const TO yo = static_cast<TO>(yv);
-            if constexpr (sizeof(TO) == 8) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
-            }
-            s_row += delta[i];
-        }
-        soff_y += static_cast<unsigned>(NGR) * qy;
-        advance_slots();
-    };
-
     TI pre_b[R];
     int mk = 0;
     while (mk < rows_total) {
-        if (fast_ok && NG == 2 && mk >= one_lo && mk + 2 * NGR <= one_hi) {
-            const int n_it = ((one_hi - NGR - mk) / NGR + 1) & ~1;  // even; requests reach one iteration further
-            soff_x = static_cast<unsigned>((s0 - B - a.buf_first + static_cast<int64_t>(mk + 2 * NGR - a_lo + g * R) * q) * kEl);
-            // rows of iteration k0+2 (the general form would request them during k0)
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                if constexpr (kEl == 8) {
-                    pre_b[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, voff_x, soff_x + i * qx, 0));
-                } else {
-                    pre_b[i] = __builtin_bit_cast(TI, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, voff_x, soff_x + i * qx, 0));
-                }
-            }
-            soff_x += static_cast<unsigned>(NGR) * qx;
-            soff_y = static_cast<unsigned>((s0 - a.out_first + static_cast<int64_t>(mk + g * R) * q) *
-                                           static_cast<int64_t>(sizeof(TO)));
-            // S is already S_k on entry: cancel group 0's first update with the cell it will read
-            double own_prev = 0.0;
-            if (g == 0)
-                own_prev = -xchg[((par ^ 1) * 2 + 1) * QP + r];
-            else
-                lds_barrier();  // group 1 idles through A(k0)
-            double delta[R], tot;
-#pragma nounroll
-            for (int it = 0; it < n_it; it += 2) {
-                skew_taps(delta, tot);
-                lds_barrier();
-                skew_rest(pre_a, delta, tot, own_prev);
-                lds_barrier();
-                skew_taps(delta, tot);
-                lds_barrier();
-                skew_rest(pre_b, delta, tot, own_prev);
-                lds_barrier();
-            }
-            if (g == 0) {  // group 1 is doing rest(k_last); bring S to the next base row
-                S += own_prev + xchg[((par ^ 1) * 2 + 1) * QP + r];
-                lds_barrier();
-            }
-            mk += n_it * NGR;
-        } else if (fast_ok && mk >= pair_lo && mk <= pair_hi) {
+        if (fast_ok && mk >= pair_lo && mk <= pair_hi) {
             // sample of (row, column 0 of the fill lanes) = s0 - B + row*q; of an output row = s0 + row*q
             soff_x = static_cast<unsigned>((s0 - B - a.buf_first + static_cast<int64_t>(mk + 2 * NGR - a_lo + g * R) * q) * kEl);
             soff_y = static_cast<unsigned>((s0 - a.out_first + static_cast<int64_t>(mk + g * R) * q) *

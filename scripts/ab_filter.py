@@ -20,12 +20,15 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=["4,2", "2,4"])
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--flags", nargs="*", default=None, help="PARRM_DEBUG_FLAGS values to A/B instead of shapes")
+    ap.add_argument("--lib", default=None, help="load this build of libparrm_hip.so instead of the in-tree one")
     args = ap.parse_args()
 
     import torch
 
     from pyparrm_amd import PARRM, _hip
 
+    if args.lib:
+        _hip._LIB_PATH = os.path.abspath(args.lib)
     _hip.require_gpu()
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn((args.chans, args.samples), dtype=torch.float64, device="cuda", generator=g)
