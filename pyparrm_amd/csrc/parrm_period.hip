@@ -124,6 +124,48 @@ __global__ void __launch_bounds__(256) fit_trig_kernel(const int64_t *idx, int n
     for (int k = K; k < kpc; ++k) w[static_cast<int64_t>(k) * n_pad] = 0.0;
 }
 
+// The same values in the sample-major "stacked" layout of fit_accum_mfma_kernel:
+// Ws[p / NCB][j][48], stacked row (p % NCB)*kpc + k (a 16-row x 4-sample MFMA operand is then four
+// 128-byte segments).  One workgroup = 64 samples x the NCB candidates of one stack (wave q =
+// candidate q): the 64 x 48 block is assembled in LDS and written out as one contiguous 24 KB run.
+// Candidates >= n_periods and samples >= n_idx are zeros.
+__global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const int64_t *idx, int n_idx, int n_pad,
+                                                                const double *periods, int n_periods, int bw,
+                                                                int kpc, int exact, double *Ws) {
+    constexpr int KS = 48, TS = 49;  // padded tile row: conflict-free b64 writes at one row per lane
+    __shared__ double tile[64 * TS];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ncb = KS / kpc;
+    const int j = blockIdx.x * 64 + lane;
+    const int p = blockIdx.y * ncb + q;
+    const int K = 2 * bw + 1;
+    double *t = tile + lane * TS + q * kpc;
+    if (j >= n_idx || p >= n_periods) {
+        for (int k = 0; k < kpc; ++k) t[k] = 0.0;
+    } else {
+        const double w0 = 6.283185307179586 / periods[p];         // (2 * np.pi / period)
+        const double ang = static_cast<double>(idx[j] + 1) * w0;  // (indices + 1) * ...
+        t[0] = 1.0;
+        double s1, c1;
+        sincos(ang, &s1, &c1);
+        double sk = s1, ck = c1;
+        for (int k = 1; k <= bw; ++k) {
+            if (exact && k > 1) sincos(static_cast<double>(k) * ang, &sk, &ck);
+            t[2 * k - 1] = sk;
+            t[2 * k] = ck;
+            const double sn = fma(sk, c1, ck * s1);
+            const double cn = fma(ck, c1, -(sk * s1));
+            sk = sn;
+            ck = cn;
+        }
+        for (int k = K; k < kpc; ++k) t[k] = 0.0;
+    }
+    __syncthreads();
+    const int rows = min(64, n_pad - blockIdx.x * 64);  // n_pad is a multiple of 16
+    double *dst = Ws + (static_cast<int64_t>(blockIdx.y) * n_pad + static_cast<int64_t>(blockIdx.x) * 64) * KS;
+    for (int e = threadIdx.x; e < rows * KS; e += blockDim.x) dst[e] = tile[(e / KS) * TS + (e % KS)];
+}
+
 // ---- Gram blocks -----------------------------------------------------------------------------
 // One workgroup = 4 waves x 12 stacked design rows = NCB = 48/KPC candidates (KPC = 12/24/48 padded
 // rows per candidate), all data columns of one 256-channel block plus the 48 stacked W columns
@@ -225,6 +267,141 @@ __global__ void __launch_bounds__(256) fit_accum_kernel(const double *Y, int64_t
     if (k0 == 0) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) out[kpc * kNCol + col[i]] = yy[i];
+    }
+}
+
+// ---- Gram blocks on the matrix cores ----------------------------------------------------------
+// Same blocking and the same output as fit_accum_kernel, computed with v_mfma_f64_16x16x4_f64:
+//   D[16 stacked rows][16 columns] += A[16 rows][4 samples] * B[4 samples][16 columns].
+// Lane l = 16*s + c holds A[row c][sample s] and B[sample s][column c] (one f64 each), so
+//   * a B operand is Y[j0+s][columns]: lane (s, c) takes the FOUR adjacent columns 64*wave + 4c + t
+//     (two 16-byte loads; tile t of the wave then holds columns 4c + t, a permutation undone when
+//     the block is written);
+//   * an A operand is Ws[j0+s][16*rt + c]: four 128-byte segments of the sample-major stack;
+//   * the Gram tiles need no extra loads: the B operand of W'W is the A operand of the other tile.
+// Operands go global/L2 -> registers directly (no LDS, no barriers), through buffer descriptors
+// whose range check supplies the zeros of the sample tail and of missing channel columns, four
+// steps ahead of their use.  Per 4-sample step a wave issues 12 (+3 Gram) MFMAs for 7 loads.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, int64_t ldy, const double *Ws,
+                                                              int n_pad, int n_idx, int n_chans, int n_periods,
+                                                              int kpc, int nsplit, double *part) {
+    constexpr int KS = 48, D = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, sj = lane >> 4;
+    const int sl = blockIdx.x, pb = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
+    const int ncb = KS / kpc;
+
+    const int tiles = n_pad / kTJ;
+    const int per = (tiles + nsplit - 1) / nsplit;
+    const int u_lo = sl * per * 4;                     // steps of 4 samples
+    const int u_hi = min(tiles, sl * per + per) * 4;
+
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Y) + static_cast<int64_t>(zb) * kYCols, 0,
+        static_cast<int>((static_cast<int64_t>(n_idx) * ldy - static_cast<int64_t>(zb) * kYCols) * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Ws) + static_cast<int64_t>(pb) * n_pad * KS, 0, n_pad * KS * 8, 0x00020000);
+    const int col0 = 64 * wv + 4 * c;                  // first of this lane's four data columns
+    const bool col_ok = zb * kYCols + col0 < n_chans;  // n_chans % 4 == 0: all four or none
+    const unsigned step_y = static_cast<unsigned>(4 * ldy * 8), step_w = 4 * KS * 8;
+    unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
+    unsigned vw = static_cast<unsigned>(((u_lo * 4 + sj) * KS + c) * 8);
+
+    d4_t acc[3][4], gacc[3];
+    double yy[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        gacc[rt] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[rt][t] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    double ra[D][3], ry[D][4];
+    auto fetch = [&](int d) {
+        const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
+        const u4_t y23 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy + 16, 0, 0);
+        ry[d][0] = __builtin_bit_cast(double, u2_t{y01.x, y01.y});
+        ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
+        ry[d][2] = __builtin_bit_cast(double, u2_t{y23.x, y23.y});
+        ry[d][3] = __builtin_bit_cast(double, u2_t{y23.z, y23.w});
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+            ra[d][rt] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw + rt * 128, 0, 0));
+        if (col_ok) vy += step_y;
+        vw += step_w;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d);
+    for (int u = u_lo; u < u_hi; u += D) {  // the slice is whole 16-sample tiles: a multiple of D steps
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double a[3], y[4];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) a[rt] = ra[d][rt];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) y[t] = ry[d][t];
+            fetch(d);  // step u + d + D (past the end of the data: zeros)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                yy[t] = fma(y[t], y[t], yy[t]);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt)
+                    acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
+            }
+            {   // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
+                // compiler shuttle the Gram accumulators between register files every step)
+                const double aw = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    gacc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, a[ct], gacc[ct], 0, 0, 0);
+            }
+        }
+    }
+    // y'y: the four sample lanes of a column hold partial sums
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        yy[t] += __shfl_xor(yy[t], 16);
+        yy[t] += __shfl_xor(yy[t], 32);
+    }
+    // D[row (lane>>4) + 4v][column lane&15] -> stacked row 16*rt + row, data column 64*wave + 4c + t
+    auto block_of = [&](int pc) -> double * {
+        return part + ((static_cast<int64_t>(pc) * nz + zb) * nsplit + sl) * static_cast<int64_t>(kpc + 1) * kNCol;
+    };
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 16 * rt + sj + 4 * v;
+            const int pc = pb * ncb + r / kpc;
+            if (pc >= n_periods) continue;
+            double *row = block_of(pc) + static_cast<int64_t>(r % kpc) * kNCol;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) row[col0 + t] = acc[rt][t][v];
+        }
+    }
+    if (wv < 3) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 16 * wv + sj + 4 * v;
+            const int pc = pb * ncb + r / kpc;
+            if (pc >= n_periods) continue;
+            double *row = block_of(pc) + static_cast<int64_t>(r % kpc) * kNCol + kYCols;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) row[16 * ct + c] = gacc[ct][v];
+        }
+    }
+    if (sj == 0) {
+        for (int q = 0; q < ncb; ++q) {
+            const int pc = pb * ncb + q;
+            if (pc >= n_periods) break;
+            double *row = block_of(pc) + static_cast<int64_t>(kpc) * kNCol;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) row[col0 + t] = yy[t];
+        }
     }
 }
 
@@ -556,7 +733,7 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
         }
     }
     g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
-    g.w_bytes = static_cast<size_t>(n_periods) * g.KP * g.n_pad * sizeof(double);
+    g.w_bytes = static_cast<size_t>(groups) * 48 * g.n_pad * sizeof(double);  // whole 48-row stacks
     g.part_bytes = static_cast<size_t>(n_periods) * g.nz * g.nsplit * g.elems * sizeof(double);
     g.red_bytes = g.nsplit > 1 ? static_cast<size_t>(n_periods) * g.nz * g.elems * sizeof(double) : 0;
     return g;
@@ -646,12 +823,26 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
     double *red = g.nsplit > 1 ? part + g.part_bytes / sizeof(double) : part;
     const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans), P = static_cast<int>(n_periods);
     static const int exact_trig = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
-    hipLaunchKernelGGL(fit_trig_kernel, dim3((g.n_pad + 255) / 256, P), dim3(256), 0, s, d_idx, n, g.n_pad, d_periods,
-                       bw, g.KP, exact_trig, wmat);
-    PARRM_HIP_CHECK(hipGetLastError());
     const int ncb = 48 / g.KP;
-    const dim3 grid(g.nsplit, (P + ncb - 1) / ncb, g.nz);
-    hipLaunchKernelGGL(fit_accum_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit, part);
+    const int groups = (P + ncb - 1) / ncb;
+    // matrix-core path: needs 16-byte column quads and 31-bit byte offsets; else the vector-ALU kernel
+    static const int accum_choice = getenv("PARRM_FIT_ACCUM") ? atoi(getenv("PARRM_FIT_ACCUM")) : 0;  // 1 = VALU, 2 = MFMA
+    const bool mfma_ok = n_chans % 4 == 0 && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 &&
+                         n_idx * ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(g.n_pad) * 48 * 8 < 0x7fff0000LL;
+    const bool use_mfma = accum_choice == 1 ? false : mfma_ok;
+    if (use_mfma)
+        hipLaunchKernelGGL(fit_trig_stacked_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * ncb), 0, s, d_idx, n,
+                           g.n_pad, d_periods, P, bw, g.KP, exact_trig, wmat);
+    else
+        hipLaunchKernelGGL(fit_trig_kernel, dim3((g.n_pad + 255) / 256, P), dim3(256), 0, s, d_idx, n, g.n_pad, d_periods,
+                           bw, g.KP, exact_trig, wmat);
+    PARRM_HIP_CHECK(hipGetLastError());
+    const dim3 grid(g.nsplit, groups, g.nz);
+    if (use_mfma)
+        hipLaunchKernelGGL(fit_accum_mfma_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
+                           part);
+    else
+        hipLaunchKernelGGL(fit_accum_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit, part);
     PARRM_HIP_CHECK(hipGetLastError());
     if (g.nsplit > 1) {
         const dim3 rgrid(static_cast<unsigned>((g.elems + 255) / 256), static_cast<unsigned>(n_periods * g.nz));
