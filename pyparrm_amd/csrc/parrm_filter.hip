@@ -185,10 +185,15 @@ void choose_stride(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan
     double best_cost = 1e300;
     int64_t best_q = 0;
     auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
+    std::vector<int64_t> taps_at;  // offsets of the taps, ascending
+    for (int64_t w = -hw; w <= hw; ++w)
+        if (tap[w + hw]) taps_at.push_back(w);
     for (int64_t q = 32; q <= kMaxBlock; ++q) {
         if (2 * hw + 3 * q > (int64_t{1} << kMaxRingLog2F64)) break;
-        int64_t nd = 0;
-        for (int64_t u = -hw - q; u <= hw; ++u) nd += tap_at(u + q) != tap_at(u);
+        // |T xor (T - q)| = 2 (|T| - #{w in T : w + q in T})
+        int64_t both = 0;
+        for (const int64_t w : taps_at) both += tap_at(w + q);
+        const int64_t nd = 2 * (static_cast<int64_t>(taps_at.size()) - both);
         const int pad = padded_delta(nd);
         if (pad == 0) continue;
         const int64_t block = (q + 63) / 64 * 64;
@@ -345,32 +350,32 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     p->off_delta = static_cast<int64_t>(tables.size());
     tables.insert(tables.end(), delta.begin(), delta.end());
     tables.push_back(0);
+    // one device allocation: weights | tables | phase table
+    const size_t wb = weights.size() * sizeof(double), tb = (tables.size() * sizeof(int32_t) + 7) & ~size_t{7},
+                 pb = phase_tab.size() * sizeof(int32_t);
+    std::vector<unsigned char> blob(wb + tb + pb);
+    std::memcpy(blob.data(), weights.data(), wb);
+    std::memcpy(blob.data() + wb, tables.data(), tables.size() * sizeof(int32_t));
+    std::memcpy(blob.data() + wb + tb, phase_tab.data(), pb);
     hipError_t e = hipGetDevice(&p->device);
-    if (e == hipSuccess) e = hipMalloc(&p->d_tables, tables.size() * sizeof(int32_t));
-    if (e == hipSuccess)
-        e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&p->d_phase_tab, phase_tab.size() * sizeof(int32_t));
-    if (e == hipSuccess)
-        e = hipMemcpy(p->d_phase_tab, phase_tab.data(), phase_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&p->d_weights, weights.size() * sizeof(double));
-    if (e == hipSuccess)
-        e = hipMemcpy(p->d_weights, weights.data(), weights.size() * sizeof(double), hipMemcpyHostToDevice);
+    void *d_blob = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_blob, blob.size());
+    if (e == hipSuccess) e = hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (p->d_weights) (void)hipFree(p->d_weights);
-        if (p->d_phase_tab) (void)hipFree(p->d_phase_tab);
-        if (p->d_tables) (void)hipFree(p->d_tables);
+        if (d_blob) (void)hipFree(d_blob);
         delete p;
         return parrm::hip_fail(e, "filter_plan_create: table upload");
     }
+    p->d_weights = static_cast<double *>(d_blob);
+    p->d_tables = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb);
+    p->d_phase_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb);
     *plan = p;
     return PARRM_OK;
 }
 
 int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
     if (!plan) return PARRM_OK;
-    if (plan->d_tables) (void)hipFree(plan->d_tables);
-    if (plan->d_weights) (void)hipFree(plan->d_weights);
-    if (plan->d_phase_tab) (void)hipFree(plan->d_phase_tab);
+    if (plan->d_weights) (void)hipFree(plan->d_weights);  // the one allocation (weights | tables | phase table)
     delete plan;
     return PARRM_OK;
 }

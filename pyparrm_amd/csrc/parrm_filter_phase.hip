@@ -566,16 +566,22 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
     double best_cost = 1e300;
     int64_t best_q = 0;
+    std::vector<int64_t> taps_at;  // offsets of the taps, ascending
+    for (int64_t w = -hw; w <= hw; ++w)
+        if (tap[w + hw]) taps_at.push_back(w);
     for (int64_t q = 64; q <= 512; ++q) {
+        // positions that matter: the taps themselves (u = w) and where a tap arrives (u = w - q)
         int64_t nd = 0;
         int guard = 0;
         bool ok = true;
-        for (int64_t u = -hw - q; u <= hw && ok; ++u) {
-            const bool is_tap = tap_at(u) != 0;
-            const bool is_delta = tap_at(u + q) != tap_at(u);
-            if (!is_tap && !is_delta) continue;
-            nd += is_delta;
-            guard = std::max(guard, std::abs(split(u, q).b));
+        for (size_t k = 0; k < taps_at.size() && ok; ++k) {
+            const int64_t w = taps_at[k];
+            nd += tap_at(w + q) == 0;                                    // u = w: tap leaves
+            guard = std::max(guard, std::abs(split(w, q).b));
+            if (tap_at(w - q) == 0) {                                    // u = w - q: tap arrives
+                ++nd;
+                guard = std::max(guard, std::abs(split(w - q, q).b));
+            }
             ok = guard <= kMaxGuard;
         }
         if (!ok || nd == 0 || (nd & 1)) continue;

@@ -440,12 +440,18 @@ class PARRM:
         (N-1)//2 (parrm.py:788-801; the `>= period + half-width` clause there never fires)."""
         limit = (self._n_samples - 1) // 2
         width, hits = self._omit_n_samples, 0
+        # the reference walks one offset at a time; the same walk in vectorised chunks
+        chunk = 4096
         while hits < 50 and width < limit:
-            width += 1
-            phase = np.mod(width, self._period)
-            hits += bool(
-                phase <= self._period_half_width or phase >= self._period + self._period_half_width
-            )
+            widths = np.arange(width + 1, min(limit, width + chunk) + 1)
+            phase = np.mod(widths, self._period)
+            hit = (phase <= self._period_half_width) | (phase >= self._period + self._period_half_width)
+            seen = hits + np.cumsum(hit)
+            done = np.flatnonzero(seen >= 50)
+            if done.size:
+                return int(widths[done[0]])
+            hits, width = int(seen[-1]), int(widths[-1])
+            chunk *= 4
         return width
 
     def _generate_filter(self) -> None:
