@@ -826,7 +826,8 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
     const int ncb = 48 / g.KP;
     const int groups = (P + ncb - 1) / ncb;
     // matrix-core path: needs 16-byte column quads and 31-bit byte offsets; else the vector-ALU kernel
-    static const int accum_choice = getenv("PARRM_FIT_ACCUM") ? atoi(getenv("PARRM_FIT_ACCUM")) : 0;  // 1 = VALU, 2 = MFMA
+    const char *accum_env = getenv("PARRM_FIT_ACCUM");  // 1 = vector-ALU kernel (read per call: tests A/B the two)
+    const int accum_choice = accum_env ? atoi(accum_env) : 0;
     const bool mfma_ok = n_chans % 4 == 0 && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 &&
                          n_idx * ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(g.n_pad) * 48 * 8 < 0x7fff0000LL;
     const bool use_mfma = accum_choice == 1 ? false : mfma_ok;

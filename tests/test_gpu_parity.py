@@ -161,6 +161,30 @@ def test_filter_kernels_agree_bitwise_free_and_shard_invariant():
     assert torch.equal(whole, again)  # deterministic run to run
 
 
+@pytest.mark.parametrize("shape", [None, "2,4", "2,3", "3,2"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_filter_interior_loop_is_bitwise_the_general_loop(monkeypatch, shape, dtype):
+    # PARRM_DEBUG_FLAGS=16 keeps every iteration on the general loop; the lean interior loop (buffer
+    # descriptors, scalar row offsets) must produce the same bits, for every workgroup shape
+    if shape is None:
+        monkeypatch.delenv("PARRM_PHASE_SHAPE", raising=False)
+    else:
+        monkeypatch.setenv("PARRM_PHASE_SHAPE", shape)
+    x = synth_recording(3, 400_003, 22000, 130, seed=11).astype(dtype)
+    taps = orc.generate_filter(169.2359, 2372, 0, "both")
+    plan = _hip.FilterPlan(taps)
+    monkeypatch.delenv("PARRM_PHASE_SHAPE", raising=False)
+    assert plan.info.phase_groups > 0
+    monkeypatch.delenv("PARRM_DEBUG_FLAGS", raising=False)
+    fast = _run_filter(plan, x, _hip.KERNEL_PHASE)
+    monkeypatch.setenv("PARRM_DEBUG_FLAGS", "16")
+    general = _run_filter(plan, x, _hip.KERNEL_PHASE)
+    monkeypatch.delenv("PARRM_DEBUG_FLAGS")
+    assert np.array_equal(fast, general)
+    _assert_filter_close(fast, orc.filter_data_direct(x.astype(np.float64), taps),
+                         rtol=FILTER_RTOL if dtype == np.float64 else 1e-5)
+
+
 def test_filter_window_and_host_streaming():
     filt = orc.generate_filter(169.23584615384616, 2372, 3, "both", None)
     hw = 2372
@@ -254,6 +278,37 @@ def test_fit_errors_many_channels_vs_oracle():
         ref = orc.grid_errors(periods, std, idx, bw, lam)
         out = _hip.fit_errors(y, d_idx, periods, bw, lam)
         np.testing.assert_allclose(out, ref, rtol=1e-9)
+
+
+def test_fit_errors_matrix_core_and_vector_paths_agree(monkeypatch):
+    # the MFMA Gram kernel (n_chans % 4 == 0) against the vector-ALU kernel and the oracle; 5 channels
+    # can only take the vector kernel
+    x = synth_recording(8, 12000, 22000, 130, seed=5)
+    std = orc.standardise_data(x, 3.0)
+    idx = np.arange(2000, 9003)
+    d = torch.from_numpy(x).cuda()
+    scale = _hip.absdiff_mean(d)
+    d_idx = torch.from_numpy(idx).cuda()
+    y = _hip.gather_standardise(d, d_idx, scale, 3.0)
+    periods = 169.2359 * (1 + np.linspace(-2e-3, 2e-3, 9))
+    for bw, lam in ((5, 1.0), (10, 1.0), (20, 1.0), (7, 0.5)):
+        ref = orc.grid_errors(periods, std, idx, bw, lam)
+        monkeypatch.delenv("PARRM_FIT_ACCUM", raising=False)
+        mfma = _hip.fit_errors(y, d_idx, periods, bw, lam)
+        monkeypatch.setenv("PARRM_FIT_ACCUM", "1")
+        valu = _hip.fit_errors(y, d_idx, periods, bw, lam)
+        monkeypatch.delenv("PARRM_FIT_ACCUM")
+        np.testing.assert_allclose(mfma, ref, rtol=1e-9)
+        np.testing.assert_allclose(valu, ref, rtol=1e-9)
+        np.testing.assert_allclose(mfma, valu, rtol=1e-11)
+    y5 = y[:, :5].contiguous()
+    ref5 = orc.grid_errors(periods, std[:5], idx, 5, 1.0)
+    np.testing.assert_allclose(_hip.fit_errors(y5, d_idx, periods, 5, 1.0), ref5, rtol=1e-9)
+    # a strided stage matrix (ldy > n_chans) on the matrix-core path
+    y_wide = torch.zeros((y.shape[0], 12), dtype=torch.float64, device="cuda")
+    y_wide[:, :8] = y
+    ref8 = orc.grid_errors(periods, std, idx, 10, 1.0)
+    np.testing.assert_allclose(_hip.fit_errors(y_wide[:, :8], d_idx, periods, 10, 1.0), ref8, rtol=1e-9)
 
 
 def test_fit_errors_singular_is_inf():
