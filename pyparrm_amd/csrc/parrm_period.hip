@@ -556,8 +556,9 @@ template <int K>
 __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
                                                               int nz, double lambda, double *err) {
     constexpr int KS = 49;  // odd row stride: lanes-as-rows accesses in the LU stay bank-conflict free
-    __shared__ double A[K * KS];    // LU factors (rows in pivot order)
-    __shared__ double G0[K * KS];   // original Gram matrix
+    constexpr int KE = (K + 2) & ~1;  // even row stride of the substitution copy: 16-byte aligned rows
+    __shared__ double A[K * KS];    // Gram matrix in, read one row per lane by the LU
+    __shared__ __attribute__((aligned(16))) double LU[K * KE];  // packed factors, rows in pivot order
     __shared__ int perm[64];        // perm[i] = original row that ended up as row i
     __shared__ int singular;
     __shared__ double wsum[4];
@@ -569,9 +570,7 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
 
     for (int e = tid; e < K * K; e += 256) {
         const int r = e / K, c = e % K;
-        const double g = base[r * kNCol + kYCols + goff + c];
-        A[r * KS + c] = g;
-        G0[r * KS + c] = g;
+        A[r * KS + c] = base[r * kNCol + kYCols + goff + c];
     }
     if (tid < 64) perm[tid] = tid;
     if (tid == 0) singular = 0;
@@ -631,7 +630,7 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
             if (lane == 0) singular = 1;
         } else if (lane < K) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) A[rank * KS + j] = arow[j];
+            for (int j = 0; j < K; ++j) LU[rank * KE + j] = arow[j];
             perm[rank] = lane;
         }
     }
@@ -653,44 +652,49 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
             double b[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) b[i] = rz[perm[i] * kNCol + tid];
+            // the factors are wave-uniform: every entry is an LDS broadcast read, so they are
+            // fetched as aligned pairs (one ds_read_b128 per two multiply-adds)
+            auto pair_at = [&](int i, int j) -> double2 {  // j even
+                return *reinterpret_cast<const double2 *>(&LU[i * KE + j]);
+            };
 #pragma unroll
             for (int i = 1; i < K; ++i) {  // L z = P r
                 double v0 = b[i], v1 = 0.0;
 #pragma unroll
                 for (int j = 0; j + 1 < i; j += 2) {
-                    v0 = fma(-A[i * KS + j], b[j], v0);
-                    v1 = fma(-A[i * KS + j + 1], b[j + 1], v1);
+                    const double2 l = pair_at(i, j);
+                    v0 = fma(-l.x, b[j], v0);
+                    v1 = fma(-l.y, b[j + 1], v1);
                 }
-                if (i & 1) v0 = fma(-A[i * KS + i - 1], b[i - 1], v0);
+                if (i & 1) v0 = fma(-LU[i * KE + i - 1], b[i - 1], v0);
                 b[i] = v0 + v1;
             }
 #pragma unroll
             for (int i = K - 1; i >= 0; --i) {  // U beta = z
                 double v0 = b[i], v1 = 0.0;
+                const int first = (i + 2) & ~1;  // first even column > i
+                if (first != i + 1 && i + 1 < K) v0 = fma(-LU[i * KE + i + 1], b[i + 1], v0);
 #pragma unroll
-                for (int j = i + 1; j + 1 < K; j += 2) {
-                    v0 = fma(-A[i * KS + j], b[j], v0);
-                    v1 = fma(-A[i * KS + j + 1], b[j + 1], v1);
+                for (int j = first; j + 1 < K; j += 2) {
+                    const double2 u = pair_at(i, j);
+                    v0 = fma(-u.x, b[j], v0);
+                    v1 = fma(-u.y, b[j + 1], v1);
                 }
-                if ((K - 1 - i) & 1) v0 = fma(-A[i * KS + K - 1], b[K - 1], v0);
-                b[i] = (v0 + v1) / A[i * KS + i];
+                if (first < K && ((K - first) & 1)) v0 = fma(-LU[i * KE + K - 1], b[K - 1], v0);
+                b[i] = (v0 + v1) / LU[i * KE + i];
             }
-            double t1 = 0.0, t2 = 0.0, reg = 0.0;
+            // |y - W beta|^2 = y'y - 2 beta'r + beta'G beta, and beta'G beta = beta'r up to the LU's
+            // backward error (relative eps * cond(G); G is a Gram matrix of near-orthogonal sinusoids),
+            // i.e. to the rounding the three-term form carries anyway -- so the K x K quadratic form,
+            // half of this phase, is not evaluated
+            double t1 = 0.0, reg = 0.0;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 t1 = fma(b[i], rz[i * kNCol + tid], t1);
-                double g0 = 0.0, g1 = 0.0;
-#pragma unroll
-                for (int j = 0; j + 1 < K; j += 2) {
-                    g0 = fma(G0[i * KS + j], b[j], g0);
-                    g1 = fma(G0[i * KS + j + 1], b[j + 1], g1);
-                }
-                g0 = fma(G0[i * KS + K - 1], b[K - 1], g0);  // K is odd
-                t2 = fma(b[i], g0 + g1, t2);
                 reg += (lambda * static_cast<double>(i + 1) / ksum) * (b[i] * b[i]);  // :585-586,:595
             }
             const double yy = rz[KP * kNCol + tid];
-            e_c = (yy - 2.0 * t1 + t2) / static_cast<double>(n_idx) + reg;
+            e_c = (yy - t1) / static_cast<double>(n_idx) + reg;
         }
         const double v = parrm::wave_sum(e_c);
         __syncthreads();
