@@ -94,6 +94,7 @@ class PARRM:
         self._check_init_inputs(data, sampling_freq, artefact_freq, verbose)
         self._n_chans, self._n_samples = (int(s) for s in self._data.shape)
         self._d_data = None  # device copy of a host recording (lazy)
+        self._d_data_src = None  # the host array object that copy was made from
         self._d_scale = None
         self._plan = None
         self._trace = None
@@ -149,19 +150,23 @@ class PARRM:
             if t.dtype not in (torch.float32, torch.float64):
                 t = t.to(torch.float64)
             return t if t.stride(-1) == 1 else t.contiguous()
-        if own and self._d_data is not None:
+        # the cache belongs to one host array OBJECT: the reference's explorer rebinds `_data` to a
+        # time slice (_plotting.py:140-141), after which the old device copy must not be served
+        if own and self._d_data is not None and self._d_data_src is src:
             return self._d_data
         host = src
         if host.dtype not in (np.float32, np.float64):
             host = host.astype(np.float64)  # the reference promotes through float64 arithmetic
         t = torch.from_numpy(np.ascontiguousarray(host)).cuda()
         if own:
-            self._d_data = t
+            self._d_data, self._d_data_src = t, src
+            self._d_scale = None
         return t
 
     def release_device_cache(self) -> None:
         """Drop the cached device copy of a host recording (e.g. after mutating ``data``)."""
         self._d_data = None
+        self._d_data_src = None
         self._d_scale = None
 
     # ------------------------------------------------------------------ find_period (a2-a8)

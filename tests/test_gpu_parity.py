@@ -397,6 +397,33 @@ def test_facade_reference_smoke(n_chans, n_samples, half):
     )
 
 
+def test_explorer_protocol_on_private_surface():
+    # what the reference's parameter explorer does to a PARRM object (_plotting.py:111-200, 360-361,
+    # 568-584): silence it, rebind `_data` to a time slice, re-validate defaults, then per widget event
+    # poke the four filter settings, regenerate the filter and re-filter
+    x = synth_recording(2, 60000, 22000, 130, seed=9)
+    p = PARRM(x, 22000, 130, verbose=True)
+    p._period = np.float64(169.2359)
+    assert p._period is not None
+    p._verbose = False
+    time_range = np.arange(5000, 45000)
+    p._data = p._data[:, time_range]
+    p._n_samples = p._data.shape[1]
+    p._check_sort_create_filter_inputs(None, 0, "both", None)
+    assert (p._period_half_width, p._filter_direction, p._omit_n_samples) == (p._period / 50, "both", 0)
+    hw0 = p._filter_half_width
+    for hw, phw, omit, direction in ((hw0, p._period / 50, 0, "both"), (1500, 2.0, 10, "past"),
+                                      (900, 4.5, 0, "future"), (hw0, 1.0, 3, "both")):
+        p._filter_half_width, p._period_half_width = hw, phw
+        p._omit_n_samples, p._filter_direction = omit, direction
+        p._generate_filter()
+        out = p.filter_data()
+        taps = orc.generate_filter(p._period, hw, omit, direction, phw)
+        assert np.array_equal(p.filter, taps)
+        assert out.shape == (p._n_chans, p._n_samples)
+        _assert_filter_close(out, orc.filter_data_direct(x[:, time_range], taps))
+
+
 def test_facade_device_tensor_roundtrip():
     x = synth_recording(4, 50000, 22000, 130, seed=6)
     d = torch.from_numpy(x).cuda()
