@@ -142,8 +142,14 @@ def check(rc: int, what: str = "") -> None:
         raise HipLibraryError(f"{what or 'parrm_hip'} failed (code {rc}): {msg}")
 
 
+_gpu_checked = None  # the torch module once a usable HIP device has been seen
+
+
 def require_gpu():
     """Return the torch module after making sure a HIP device is usable; raise loudly otherwise."""
+    global _gpu_checked
+    if _gpu_checked is not None:
+        return _gpu_checked
     L = lib()
     import torch
 
@@ -154,11 +160,35 @@ def require_gpu():
             "no MI355X/HIP device is visible: pyparrm_amd runs find_period/filter_data on the GPU "
             "only (there is no CPU fallback)."
         )
+    _gpu_checked = torch
     return torch
 
 
 def _stream_ptr(torch) -> int:
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # no Stream object per call
+    if raw is not None:
+        return int(raw(torch.cuda.current_device()))
     return int(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device:
+    """``with torch.cuda.device(dev)`` that costs nothing when ``dev`` is already current (the
+    optimiser makes ~100 small calls per ``find_period``)."""
+
+    __slots__ = ("_ctx",)
+
+    def __init__(self, torch, device):
+        index = device.index
+        self._ctx = None if index is None or index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*exc)
+        return False
 
 
 def _dtype_code(t) -> int:
@@ -371,7 +401,7 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
         nbytes = ws.nbytes(n_idx, n_chans, n_per, bandwidth) + 16 * n_per
         buf = ws.get(nbytes, y.device)
         out = np.empty(n_per, dtype=np.float64)
-        with torch.cuda.device(y.device):
+        with _on_device(torch, y.device):
             check(
                 L.parrm_fit_errors_host(
                     y.data_ptr(), y.stride(0), idx.data_ptr(), n_idx, n_chans,

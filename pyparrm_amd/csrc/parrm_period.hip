@@ -11,8 +11,10 @@
 // by FP64 vector FMA + sincos issue, not by HBM: Y (<= 51 MB) stays in L2 / Infinity Cache.
 // No MFMA: FP64 matrix and vector peaks are equal on MI355X (hard part 4).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "parrm_common.h"
@@ -743,6 +745,54 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
     return g;
 }
 
+// ---- host hand-off of the small optimiser batches ---------------------------------------------
+// One Nelder-Mead step is a handful of candidates; the D2H copy + stream synchronise of the plain
+// path cost more host time (~40 us) than some of the kernels.  Instead a one-wave kernel at the end
+// of the stream copies the errors into a pinned, device-mapped staging block and then raises a
+// sequence flag (system-scope release) that the host spins on.
+__global__ void __launch_bounds__(64) fit_publish_kernel(const double *err, int n, double *host_err,
+                                                          volatile unsigned long long *flag,
+                                                          unsigned long long seq) {
+    for (int i = threadIdx.x; i < n; i += 64) host_err[i] = err[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *flag = seq;
+        __threadfence_system();
+    }
+}
+
+struct HostStage {
+    static constexpr int64_t kCap = 4096;  // candidates per staged call; larger batches use the copy path
+    double *h = nullptr;                   // [kCap] (unused) | [kCap] errors | flag
+    double *d = nullptr;                   // the same block through the device's mapping
+    int device = -1;
+    unsigned long long seq = 0;
+    ~HostStage() {
+        if (h) (void)hipHostFree(h);
+    }
+    bool ready(int dev) {
+        if (h && device == dev) return true;
+        if (h) {
+            (void)hipHostFree(h);
+            h = nullptr;
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, (2 * kCap + 8) * sizeof(double), hipHostMallocMapped) != hipSuccess) return false;
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
+            (void)hipHostFree(p);
+            return false;
+        }
+        h = static_cast<double *>(p);
+        d = static_cast<double *>(dp);
+        device = dev;
+        *reinterpret_cast<volatile unsigned long long *>(h + 2 * kCap) = 0;
+        return true;
+    }
+};
+thread_local HostStage g_stage;
+
 }  // namespace
 
 extern "C" {
@@ -891,6 +941,40 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
     hipStream_t s = parrm::as_stream(stream);
     double *d_per = reinterpret_cast<double *>(static_cast<char *>(d_workspace) + inner);
     double *d_err = d_per + n_periods;
+    int dev = 0;
+    PARRM_HIP_CHECK(hipGetDevice(&dev));
+    if (n_periods <= HostStage::kCap && !getenv("PARRM_FIT_COPY_PATH") && g_stage.ready(dev)) {
+        HostStage &st = g_stage;
+        // (the periods still go through a device copy: every workgroup of the trig kernel reads them,
+        // which would be one uncached PCIe read per wave from mapped host memory)
+        PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
+        const int rc = parrm_fit_errors(d_y, ldy, d_idx, n_idx, n_chans, d_per, n_periods, bw, lambda, d_err, d_workspace,
+                                        inner, stream);
+        if (rc != PARRM_OK) return rc;
+        const unsigned long long seq = ++st.seq;
+        volatile unsigned long long *h_flag = reinterpret_cast<volatile unsigned long long *>(st.h + 2 * HostStage::kCap);
+        hipLaunchKernelGGL(fit_publish_kernel, dim3(1), dim3(64), 0, s, d_err, static_cast<int>(n_periods),
+                           st.d + HostStage::kCap,
+                           reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap), seq);
+        PARRM_HIP_CHECK(hipGetLastError());
+        // spin on the flag; look at the stream now and then so that a failed launch cannot hang us
+        for (unsigned spins = 0; *h_flag != seq; ++spins) {
+            if ((spins & 0xffff) == 0xffff) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) {
+                    if (*h_flag == seq) break;
+                    PARRM_HIP_CHECK(hipStreamSynchronize(s));
+                    PARRM_REQUIRE(*h_flag == seq, "fit_errors_host: the stream drained without publishing the errors");
+                    break;
+                }
+                if (q != hipErrorNotReady) return parrm::hip_fail(q, "fit_errors_host: stream");
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(h_err, st.h + HostStage::kCap, n_periods * sizeof(double));
+        return PARRM_OK;
+    }
     PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
     const int rc = parrm_fit_errors(d_y, ldy, d_idx, n_idx, n_chans, d_per, n_periods, bw, lambda, d_err, d_workspace,
                                     inner, stream);
