@@ -468,6 +468,52 @@ def test_config2_properties_64ch_1M():
     assert float((yg - ya[:2]).abs().max()) < 1e-11
 
 
+def test_config3_properties_256ch_10M():
+    """BASELINE config 3 (256 ch x 10 Msample f64, the bench workload, 61 GB of device buffers):
+    size-independent properties at full size + closed-form checks of whole rows and of windows at
+    the stretch seams, the recording edges and random places."""
+    n_chans, n_samples = 256, 10_000_000
+    filt = orc.generate_filter(169.23584615384616, 2372, 0, "both", None)
+    hw = 2372
+    plan = _hip.FilterPlan(filt)
+    assert plan.info.kernel == _hip.KERNEL_PHASE
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((n_chans, n_samples), dtype=torch.float64, device="cuda", generator=g)
+    ya = plan.apply(a)
+    # linearity, through in-place combinations (no fourth full-size buffer)
+    b = torch.randn((n_chans, n_samples), dtype=torch.float64, device="cuda", generator=g)
+    yb = plan.apply(b)
+    b.mul_(-0.75).add_(a, alpha=2.5)          # b <- 2.5 a - 0.75 b
+    yb.mul_(-0.75).add_(ya, alpha=2.5)        # expected filter(b)
+    yc = plan.apply(b)
+    assert float((yc - yb).abs().max()) < 1e-11
+    del b, yb, yc
+    # determinism: a second launch gives the same bits
+    assert torch.equal(plan.apply(a), ya)
+    # whole rows against the closed form
+    rows = [0, 100, 255]
+    ref = orc.filter_data_direct(a[rows].cpu().numpy(), filt)
+    _assert_filter_close(ya[rows].cpu().numpy(), ref)
+    # windows of every channel: edges, the first stretch seams, random interior places
+    stretch = (131072 // 169 // 8 * 8) * 169  # rows per stretch are a multiple of NG*R = 8
+    rng = np.random.default_rng(5)
+    starts = [0, n_samples - 4000, stretch - 2000, 2 * stretch - 2000] + list(rng.integers(hw, n_samples - 4000 - hw, 6))
+    chans = torch.from_numpy(rng.permutation(n_chans)[:16]).cuda()
+    for s0 in starts:
+        lo, hi = max(0, s0 - hw), min(n_samples, s0 + 4000 + hw)
+        xs = a[chans][:, lo:hi].cpu().numpy()
+        # closed form on the window; only positions whose taps all lie inside the window (or at a
+        # true recording edge) are comparable
+        ref = orc.filter_data_direct(xs, filt)
+        got = ya[chans][:, lo:hi].cpu().numpy()
+        keep = np.ones(hi - lo, dtype=bool)
+        if lo > 0:
+            keep[:hw] = False
+        if hi < n_samples:
+            keep[-hw:] = False
+        _assert_filter_close(got, ref, mask=keep)
+
+
 # ---------------------------------------------------------------------------- input robustness
 def test_facade_input_kinds():
     """float32 / integer / non-contiguous recordings behave like the reference's dtype rules."""
