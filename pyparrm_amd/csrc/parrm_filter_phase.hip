@@ -265,8 +265,8 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
         for (int t = 0; t < 2 * DP; ++t) e[t] = trow[t];
     };
+    fetch_table(sl_top);  // first iteration's row; later rows are requested right after each barrier
     auto tap_sums = [&](double (&delta)[R], const bool skip_taps) {
-        fetch_table(sl_top);
         double accp[R], accm[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -353,25 +353,27 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     };
     // 4. chain the groups after the barrier: returns S at this wave's first row and moves S to the
     // next iteration's base row
-    // (weights instead of selects: fma(1, t, s) rounds like s + t and fma(0, t, s) is s)
+    // Straight-line for any NG <= 4: all four cells are read at once (groups beyond NG re-read the last
+    // real one) and combined with wave-uniform 0/1 weights -- fma(1, t, s) rounds like s + t and
+    // fma(0, t, s) is s -- instead of per-group branches, which serialised one LDS round trip each.
     const double w0 = g > 0 ? 1.0 : 0.0, w1 = g > 1 ? 1.0 : 0.0, w2 = g > 2 ? 1.0 : 0.0;
-    auto chain = [&]() -> double {
+    const double u1 = NG > 1 ? 1.0 : 0.0, u2 = NG > 2 ? 1.0 : 0.0, u3 = NG > 3 ? 1.0 : 0.0;
+    const int xg1 = (NG > 1 ? 1 : NG - 1) * QP, xg2 = (NG > 2 ? 2 : NG - 1) * QP, xg3 = (NG > 3 ? 3 : NG - 1) * QP;
+    auto chain_reads = [&](double (&t)[4]) {
         const double *xc = xchg + (par * NG) * QP + r;
-        double s_row = S, s_all = xc[0];
-        if (NG > 1) {
-            s_row = fma(w0, s_all, s_row);
-            s_all += xc[QP];
-        }
-        if (NG > 2) {
-            s_row = fma(w1, xc[QP], s_row);
-            s_all += xc[2 * QP];
-        }
-        if (NG > 3) {
-            s_row = fma(w2, xc[2 * QP], s_row);
-            s_all += xc[3 * QP];
-        }
-        S += s_all;
+        t[0] = xc[0];
+        t[1] = xc[xg1];
+        t[2] = xc[xg2];
+        t[3] = xc[xg3];
+    };
+    auto chain_math = [&](const double (&t)[4]) -> double {
+        const double s_row = fma(w2, t[2], fma(w1, t[1], fma(w0, t[0], S)));
+        S += fma(u3, t[3], fma(u2, t[2], fma(u1, t[1], t[0])));
         return s_row;
+    };
+    auto next_top = [&]() -> int {
+        const int nt = sl_top + NGR;
+        return nt >= M ? nt - M : nt;
     };
     // LDS-only barrier: a plain __syncthreads() also waits vmcnt(0), i.e. for the global loads
     // requested above and for the previous iteration's output stores, once per iteration
@@ -420,7 +422,10 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             }
         }
         if (!(p.debug & 8)) lds_barrier();
-        double s_row = chain();
+        double tg[4];
+        chain_reads(tg);
+        fetch_table(next_top());  // next iteration's tap offsets: one wait covers them and the cells
+        double s_row = chain_math(tg);
         // 5. outputs.  Rows that are interior to the recording and to the stretch take a branch-free
         // path (the test is wave-uniform); edge rows go through emit().
         if (!(p.debug & 2)) {
@@ -502,7 +507,10 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             }
         }
         lds_barrier();
-        double s_row = chain();
+        double tg[4];
+        chain_reads(tg);
+        fetch_table(next_top());  // next iteration's tap offsets: one wait covers them and the cells
+        double s_row = chain_math(tg);
         // 5. outputs
 #pragma unroll
         for (int i = 0; i < R; ++i) {
