@@ -105,6 +105,15 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
                               int64_t buf_len, int64_t out_first, int64_t out_len,
                               int64_t n_total, int64_t ldx, int64_t ldy, void *stream);
 
+/* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host page-locks the
+ * caller's buffers itself when they are not locked yet, which costs ~20 ms per GiB per call (more
+ * than moving the data); a caller that filters the same recording repeatedly -- the reference's
+ * parameter explorer re-filters on every widget event (_utils/_plotting.py:568-584) -- locks it
+ * once instead.  Buffers that already are pinned (e.g. by the caller's allocator) are detected and
+ * left alone by both entry points. */
+int parrm_host_pin(void *h_ptr, size_t bytes);
+int parrm_host_unpin(void *h_ptr);
+
 /* Host-resident recording, streamed through the device in time chunks of `chunk_samples`
  * (0 = pick) with pinned double buffers and two streams; synchronous. */
 int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtype, void *h_y,

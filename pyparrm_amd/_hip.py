@@ -30,6 +30,8 @@ SYMBOLS = (
     "parrm_filter_apply",
     "parrm_filter_apply_window",
     "parrm_filter_host",
+    "parrm_host_pin",
+    "parrm_host_unpin",
     "parrm_absdiff_workspace_bytes",
     "parrm_absdiff_mean",
     "parrm_gather_standardise",
@@ -118,6 +120,10 @@ def lib() -> C.CDLL:
         L.parrm_filter_apply_window.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, vp]
         L.parrm_filter_host.restype = i32
         L.parrm_filter_host.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64]
+        L.parrm_host_pin.restype = i32
+        L.parrm_host_pin.argtypes = [vp, C.c_size_t]
+        L.parrm_host_unpin.restype = i32
+        L.parrm_host_unpin.argtypes = [vp]
         L.parrm_absdiff_workspace_bytes.restype = C.c_size_t
         L.parrm_absdiff_workspace_bytes.argtypes = [i64, i64]
         L.parrm_absdiff_mean.restype = i32
@@ -285,13 +291,21 @@ class FilterPlan:
             )
         return out
 
-    def apply_host(self, x: np.ndarray, out_dtype=np.float64, chunk_samples: int = 0) -> np.ndarray:
-        """Stream a host-resident recording through the device in time chunks."""
+    def apply_host(self, x: np.ndarray, out_dtype=np.float64, chunk_samples: int = 0, out=None) -> np.ndarray:
+        """Stream a host-resident recording through the device in time chunks.
+
+        ``out`` (optional) receives the result; pass arrays locked with :func:`pin_host` when the
+        same buffers are filtered repeatedly -- page-locking costs more than the transfer."""
         require_gpu()
         if x.dtype not in (np.float32, np.float64):
             x = x.astype(np.float64)
         x = np.ascontiguousarray(x)
-        y = np.empty(x.shape, dtype=out_dtype)
+        if out is None:
+            y = np.empty(x.shape, dtype=out_dtype)
+        else:
+            y = out
+            if y.shape != x.shape or not y.flags.c_contiguous or y.dtype not in (np.float32, np.float64):
+                raise ValueError("`out` must be a C-contiguous float32/float64 array of the input's shape")
         code_x = F64 if x.dtype == np.float64 else F32
         code_y = F64 if y.dtype == np.float64 else F32
         check(
@@ -302,6 +316,18 @@ class FilterPlan:
             "parrm_filter_host",
         )
         return y
+
+
+def pin_host(array: np.ndarray) -> None:
+    """Page-lock a host array for :meth:`FilterPlan.apply_host` (no-op when it already is)."""
+    require_gpu()
+    check(lib().parrm_host_pin(array.ctypes.data_as(C.c_void_p), array.nbytes), "parrm_host_pin")
+
+
+def unpin_host(array: np.ndarray) -> None:
+    """Undo :func:`pin_host` (no-op for memory that is not page-locked)."""
+    require_gpu()
+    check(lib().parrm_host_unpin(array.ctypes.data_as(C.c_void_p)), "parrm_host_unpin")
 
 
 def absdiff_mean(x):

@@ -70,6 +70,31 @@ int parrm_hip_device_count(int *count) {
 // half-width halo on each side (stencil locality, SURVEY.md 5 "long-context").  Two streams, two
 // device buffer pairs: upload/compute/download of chunk k+1 overlaps chunk k.  The host buffers are
 // page-locked for the duration of the call so the copies are true async DMA.
+// true when the runtime already knows `p` as page-locked host memory
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t attr{};
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain pageable memory reports an error here
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int parrm_host_pin(void *h_ptr, size_t bytes) {
+    PARRM_REQUIRE(h_ptr && bytes > 0, "host_pin: NULL or empty buffer");
+    if (is_pinned_host(h_ptr)) return PARRM_OK;
+    PARRM_HIP_CHECK(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return PARRM_OK;
+}
+
+int parrm_host_unpin(void *h_ptr) {
+    PARRM_REQUIRE(h_ptr, "host_unpin: NULL buffer");
+    if (!is_pinned_host(h_ptr)) return PARRM_OK;
+    PARRM_HIP_CHECK(hipHostUnregister(h_ptr));
+    return PARRM_OK;
+}
+
 int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtype, void *h_y, int y_dtype,
                       int64_t n_chans, int64_t n_samples, int64_t ldx, int64_t ldy, int64_t chunk_samples) {
     PARRM_REQUIRE(plan && h_x && h_y, "filter_host: NULL argument");
@@ -102,8 +127,9 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     // page-lock the caller's buffers (no staging copy); unlock on every exit path
     const size_t x_bytes = static_cast<size_t>((n_chans - 1) * ldx + n_samples) * xs;
     const size_t y_bytes = static_cast<size_t>((n_chans - 1) * ldy + n_samples) * ys;
-    const bool pin_x = hipHostRegister(const_cast<void *>(h_x), x_bytes, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_y = hipHostRegister(h_y, y_bytes, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_x = !is_pinned_host(h_x) &&
+                       hipHostRegister(const_cast<void *>(h_x), x_bytes, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_y = !is_pinned_host(h_y) && hipHostRegister(h_y, y_bytes, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();  // a refused registration only costs bandwidth
     auto unpin = [&]() {
         if (pin_x) (void)hipHostUnregister(const_cast<void *>(h_x));

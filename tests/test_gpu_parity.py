@@ -204,6 +204,21 @@ def test_filter_window_and_host_streaming():
     _assert_filter_close(streamed, whole, rtol=1e-12)
     streamed32 = plan.apply_host(x.astype(np.float32), out_dtype=np.float32, chunk_samples=20000)
     _assert_filter_close(streamed32.astype(np.float64), whole, rtol=1e-5)
+    # caller-locked buffers (parrm_host_pin): same bits, the call leaves the locks in place
+    out = np.empty_like(x)
+    _hip.pin_host(x)
+    _hip.pin_host(out)
+    _hip.pin_host(out)  # idempotent
+    try:
+        for _ in range(2):
+            got = plan.apply_host(x, chunk_samples=13001, out=out)
+            assert got is out and np.array_equal(out, streamed)
+    finally:
+        _hip.unpin_host(out)
+        _hip.unpin_host(x)
+    _hip.unpin_host(x)  # not locked any more: a no-op
+    with pytest.raises(ValueError):
+        plan.apply_host(x, out=np.empty((2, 5)))
 
 
 def test_filter_nonfinite_outputs_are_zeroed():
