@@ -504,7 +504,7 @@ class PARRM:
             filtered = self._plan.apply_host(data)
         else:
             y = self._plan.apply(self._device_recording(data))
-            filtered = y.cpu().numpy() if isinstance(data, np.ndarray) else y
+            filtered = _hip.to_host_numpy(y) if isinstance(data, np.ndarray) else y
         self._filtered_data = filtered
         self._say("    ... Data filtered\n")
         return self._filtered_data
