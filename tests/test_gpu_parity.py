@@ -510,7 +510,7 @@ def test_config3_properties_256ch_10M():
     ref = orc.filter_data_direct(a[rows].cpu().numpy(), filt)
     _assert_filter_close(ya[rows].cpu().numpy(), ref)
     # windows of every channel: edges, the first stretch seams, random interior places
-    stretch = (131072 // 169 // 8 * 8) * 169  # rows per stretch are a multiple of NG*R = 8
+    stretch = (262144 // 169 // 8 * 8) * 169  # rows per stretch are a multiple of NG*R = 8
     rng = np.random.default_rng(5)
     starts = [0, n_samples - 4000, stretch - 2000, 2 * stretch - 2000] + list(rng.integers(hw, n_samples - 4000 - hw, 6))
     chans = torch.from_numpy(rng.permutation(n_chans)[:16]).cuda()
