@@ -51,11 +51,12 @@ __device__ inline unsigned lds_offset(const void *p) {
 // ds_read_b64 rate (MI355X_MICROARCH.md, LDS table).  The reads are software-pipelined: the asm
 // that issues batch k also waits, with a COUNTED lgkmcnt, for batch k-1 -- LDS operations return
 // in order, so "at most n outstanding" right after issuing n reads means everything older is
-// back, whatever else (LDS or scalar loads) the compiler had in flight before the statement.
+// back, whatever other LDS traffic the compiler had in flight before the statement.  (Scalar loads
+// share lgkmcnt but return out of order: the kernel keeps none in flight across the tap loop --
+// the tap-table row is requested behind the barrier and waited for before the first tap.)
 // The LDS pipe therefore never drains inside the tap loop (draining every batch measured ~45 %
 // of the LDS rate at 3 waves/SIMD).  Uses of a batch are kept below its wait by a
 // sched_barrier (the compiler does not know the asm results are asynchronous).
-#define PARRM_RD2(op, o0, o1, a, s) op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t"
 #define PARRM_RD3(op, o0, o1, o2, a, s) \
     op " %" #o0 ", %" #a "\n\t" op " %" #o1 ", %" #a " offset:" #s "\n\t" op " %" #o2 ", %" #a " offset:2*" #s "\n\t"
 #define PARRM_RD4(op, o0, o1, o2, o3, a, s)                                                              \
@@ -66,7 +67,7 @@ __device__ inline unsigned lds_offset(const void *p) {
 #define PARRM_WAITSTR(n) "s_waitcnt lgkmcnt(" #n ")"
 template <typename TI, int R, int WAIT>
 __device__ inline void tap_rows(unsigned ad, TI (&v)[R]) {
-    static_assert(WAIT == -1 || WAIT == 6 || WAIT == 9 || WAIT == 12, "wait count");
+    static_assert(WAIT == -1 || WAIT == 9 || WAIT == 12, "wait count");
     if constexpr (sizeof(TI) == 8 && R == 4) {
         if constexpr (WAIT == 12)
             asm volatile(PARRM_RD4("ds_read_b64", 0, 1, 2, 3, 4, 8) PARRM_WAITSTR(12)
@@ -88,24 +89,14 @@ __device__ inline void tap_rows(unsigned ad, TI (&v)[R]) {
         else
             asm volatile(PARRM_RD3("ds_read_b64", 0, 1, 2, 3, 8) ""
                          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
-    } else if constexpr (sizeof(TI) == 4 && R == 3) {
+    } else {
+        static_assert(R == 3 && sizeof(TI) == 4, "unsupported row-set shape (R == 2 goes through tap_pair)");
         if constexpr (WAIT == 9)
             asm volatile(PARRM_RD3("ds_read_b32", 0, 1, 2, 3, 4) PARRM_WAITSTR(9)
                          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
         else
             asm volatile(PARRM_RD3("ds_read_b32", 0, 1, 2, 3, 4) ""
                          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(ad));
-    } else if constexpr (sizeof(TI) == 8 && R == 2) {
-        if constexpr (WAIT == 6)
-            asm volatile(PARRM_RD2("ds_read_b64", 0, 1, 2, 8) PARRM_WAITSTR(6) : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
-        else
-            asm volatile(PARRM_RD2("ds_read_b64", 0, 1, 2, 8) "" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
-    } else {
-        static_assert(sizeof(TI) == 4 && R == 2, "unsupported row-set shape");
-        if constexpr (WAIT == 6)
-            asm volatile(PARRM_RD2("ds_read_b32", 0, 1, 2, 4) PARRM_WAITSTR(6) : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
-        else
-            asm volatile(PARRM_RD2("ds_read_b32", 0, 1, 2, 4) "" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad));
     }
 }
 
