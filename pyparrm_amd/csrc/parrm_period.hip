@@ -554,6 +554,16 @@ __global__ void __launch_bounds__(256) fit_solve_kernel(const double *red, int n
 //   * every thread then solves one channel with its right-hand side in REGISTERS (fully unrolled
 //     substitution; the factors come from LDS as broadcast reads), and evaluates the quadratic form.
 // Measured on the K = 41 polish batches: 210 us -> see profiles.
+// max over a DPP-shuffled copy of a 64-bit key (rows not in ROW_MASK keep their value)
+template <int CTRL, int ROW_MASK>
+__device__ inline unsigned long long dpp_max_u64(unsigned long long v) {
+    const int lo = static_cast<int>(v), hi = static_cast<int>(v >> 32);
+    const unsigned olo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false));
+    const unsigned ohi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false));
+    const unsigned long long o = (static_cast<unsigned long long>(ohi) << 32) | olo;
+    return o > v ? o : v;
+}
+
 template <int K>
 __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
                                                               int nz, double lambda, double *err) {
@@ -593,19 +603,23 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
         bool sing = false;
 #pragma unroll
         for (int col = 0; col < K; ++col) {
-            double v = done ? -1.0 : fabs(arow[col]);
+            double v = fabs(arow[col]);
             if (v != v) v = 1e308;  // a NaN: let it through as the pivot
-            int best = lane;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_xor(v, off, 64);
-                const int ob = __shfl_xor(best, off, 64);
-                if (ov > v || (ov == v && ob < best)) {
-                    v = ov;
-                    best = ob;
-                }
-            }
-            const int pl = __builtin_amdgcn_readfirstlane(best);  // pivot lane
+            // arg-max as ONE unsigned 64-bit max over the wave: a non-negative double orders like its
+            // bit pattern; its low 6 bits are replaced by 63 - lane (ties -> lowest row; values that
+            // differ only below 2^-46 relative count as ties -- either is as good a pivot), +64 keeps
+            // every candidate above the 0 of the lanes that have already served.  Row-wise DPP
+            // reduction (quad swaps, half-mirror, mirror, two row broadcasts: rocPRIM's gfx9 scheme)
+            // instead of six rounds of three ds_bpermutes.
+            unsigned long long key =
+                done ? 0ull : ((static_cast<unsigned long long>(__double_as_longlong(v)) & ~63ull) | (63u - lane)) + 64ull;
+            key = dpp_max_u64<0xB1, 0xf>(key);   // quad_perm [1,0,3,2]
+            key = dpp_max_u64<0x4E, 0xf>(key);   // quad_perm [2,3,0,1]
+            key = dpp_max_u64<0x141, 0xf>(key);  // row_half_mirror
+            key = dpp_max_u64<0x140, 0xf>(key);  // row_mirror
+            key = dpp_max_u64<0x142, 0xa>(key);  // row_bcast:15 into rows 1 and 3
+            key = dpp_max_u64<0x143, 0xc>(key);  // row_bcast:31 into rows 2 and 3
+            const int pl = 63 - (__builtin_amdgcn_readlane(static_cast<int>(key), 63) & 63);  // pivot lane
             double prow[K];
 #pragma unroll
             for (int j = col; j < K; ++j) {
