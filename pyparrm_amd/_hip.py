@@ -375,17 +375,19 @@ def gather_standardise(x, idx, scale, outlier_boundary: float):
     torch = require_gpu()
     _check_rows(x, "x")
     n_chans, n_samples = x.shape
-    y = torch.empty((idx.shape[0], n_chans), dtype=torch.float64, device=x.device)
+    # rows padded to whole column quads (zeros): the matrix-core Gram kernel reads 16-byte quads
+    ld = (n_chans + 3) // 4 * 4
+    y = (torch.zeros if ld != n_chans else torch.empty)((idx.shape[0], ld), dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
         check(
             lib().parrm_gather_standardise(
                 x.data_ptr(), _dtype_code(x), n_chans, n_samples, max(x.stride(0), n_samples),
                 idx.data_ptr(), idx.shape[0], scale.data_ptr(), float(outlier_boundary),
-                y.data_ptr(), n_chans, _stream_ptr(torch),
+                y.data_ptr(), ld, _stream_ptr(torch),
             ),
             "parrm_gather_standardise",
         )
-    return y
+    return y[:, :n_chans]
 
 
 class FitWorkspace:

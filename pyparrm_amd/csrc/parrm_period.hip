@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(Ws) + static_cast<int64_t>(pb) * n_pad * KS, 0, n_pad * KS * 8, 0x00020000);
     const int col0 = 64 * wv + 4 * c;                  // first of this lane's four data columns
-    const bool col_ok = zb * kYCols + col0 < n_chans;  // n_chans % 4 == 0: all four or none
+    // a quad may straddle n_chans: its extra columns come from the row's padding (or, with a tight
+    // ldy, from the next row / the zero tail) and land in result columns that nothing reads
+    const bool col_ok = zb * kYCols + col0 < n_chans;
     const unsigned step_y = static_cast<unsigned>(4 * ldy * 8), step_w = 4 * KS * 8;
     unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
     unsigned vw = static_cast<unsigned>(((u_lo * 4 + sj) * KS + c) * 8);
@@ -893,10 +895,11 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
     static const int exact_trig = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
     const int ncb = 48 / g.KP;
     const int groups = (P + ncb - 1) / ncb;
-    // matrix-core path: needs 16-byte column quads and 31-bit byte offsets; else the vector-ALU kernel
+    // matrix-core path: needs 16-byte aligned column quads (even ldy) and 31-bit byte offsets; else the
+    // vector-ALU kernel
     const char *accum_env = getenv("PARRM_FIT_ACCUM");  // 1 = vector-ALU kernel (read per call: tests A/B the two)
     const int accum_choice = accum_env ? atoi(accum_env) : 0;
-    const bool mfma_ok = n_chans % 4 == 0 && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 &&
+    const bool mfma_ok = ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 &&
                          n_idx * ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(g.n_pad) * 48 * 8 < 0x7fff0000LL;
     const bool use_mfma = accum_choice == 1 ? false : mfma_ok;
     if (use_mfma)

@@ -316,9 +316,19 @@ def test_fit_errors_matrix_core_and_vector_paths_agree(monkeypatch):
         np.testing.assert_allclose(mfma, ref, rtol=1e-9)
         np.testing.assert_allclose(valu, ref, rtol=1e-9)
         np.testing.assert_allclose(mfma, valu, rtol=1e-11)
-    y5 = y[:, :5].contiguous()
+    # 5 channels: a contiguous [n, 5] matrix (odd row stride) can only take the vector kernel; the
+    # same columns inside rows padded to whole quads take the matrix cores (quad straddles n_chans)
     ref5 = orc.grid_errors(periods, std[:5], idx, 5, 1.0)
+    y5 = y[:, :5].contiguous()
     np.testing.assert_allclose(_hip.fit_errors(y5, d_idx, periods, 5, 1.0), ref5, rtol=1e-9)
+    np.testing.assert_allclose(_hip.fit_errors(y[:, :5], d_idx, periods, 5, 1.0), ref5, rtol=1e-9)
+    for n_ch in (1, 2, 3, 6, 7):
+        xs = x[:n_ch]
+        ds = torch.from_numpy(np.ascontiguousarray(xs)).cuda()
+        ys = _hip.gather_standardise(ds, d_idx, _hip.absdiff_mean(ds), 3.0)
+        assert ys.shape == (idx.shape[0], n_ch) and ys.stride(0) % 4 == 0
+        refs = orc.grid_errors(periods, orc.standardise_data(xs, 3.0), idx, 10, 1.0)
+        np.testing.assert_allclose(_hip.fit_errors(ys, d_idx, periods, 10, 1.0), refs, rtol=1e-9)
     # a strided stage matrix (ldy > n_chans) on the matrix-core path
     y_wide = torch.zeros((y.shape[0], 12), dtype=torch.float64, device="cuda")
     y_wide[:, :8] = y
