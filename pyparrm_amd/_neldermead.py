@@ -33,7 +33,13 @@ class _MaxFun(Exception):
 
 
 class _Start:
-    """State of one SciPy Nelder-Mead run on a scalar parameter."""
+    """State of one SciPy Nelder-Mead run on a scalar parameter.
+
+    The two vertices and their values are kept as Python floats (IEEE doubles, the arithmetic
+    NumPy's float64 scalars use): a lock-step batch advances up to five of these objects, and the
+    dozen NumPy calls per object and iteration that 2-element arrays cost (~15 us) were most of the
+    host time between two device batches.  Ordering follows ``np.argsort`` on two elements: stable,
+    NaN last."""
 
     def __init__(self, x0, xatol, fatol, maxiter, maxfun):
         x0 = np.atleast_1d(x0).flatten()
@@ -41,12 +47,15 @@ class _Start:
             x0 = x0.astype(np.float64)
         if x0.shape[0] != 1:
             raise ValueError("only scalar parameters are supported")
+        if x0.dtype != np.float64:
+            raise TypeError("the batched Nelder-Mead works in float64 (got a %s start)" % x0.dtype)
         self.xatol, self.fatol = xatol, fatol
         self.maxiter = 200 if maxiter is None else maxiter
         self.maxfun = 200 if maxfun is None else maxfun
-        y = x0[0] * (1 + NONZDELT) if x0[0] != 0 else x0.dtype.type(ZDELT)
-        self.sim = np.array([x0[0], y], dtype=x0.dtype)
-        self.fsim = np.full(2, np.inf)
+        first = float(x0[0])
+        second = first * (1 + NONZDELT) if first != 0 else ZDELT
+        self.sim = [first, second]
+        self.fsim = [np.inf, np.inf]
         self.fcalls = 0
         self.iterations = 0  # 0: initial simplex not evaluated yet
         self.done = False
@@ -54,26 +63,26 @@ class _Start:
     # -- the abscissae the next step may need -------------------------------------------------
     def wanted(self):
         if self.iterations == 0:
-            return [self.sim[0], self.sim[1]]
-        xbar, worst = self.sim[0], self.sim[1]
+            return list(self.sim)
+        xbar, worst = self.sim
         self._xr = (1 + RHO) * xbar - RHO * worst
         self._xe = (1 + RHO * CHI) * xbar - RHO * CHI * worst
         self._xc = (1 + PSI * RHO) * xbar - PSI * RHO * worst
         self._xcc = (1 - PSI) * xbar + PSI * worst
-        self._xs = self.sim[0] + SIGMA * (self.sim[1] - self.sim[0])
+        self._xs = xbar + SIGMA * (worst - xbar)
         return [self._xr, self._xe, self._xc, self._xcc, self._xs]
 
     def _f(self, table, x):
         if self.fcalls >= self.maxfun:  # SciPy's wrapper refuses the call
             raise _MaxFun()
         self.fcalls += 1
-        x = float(x)
         return table[x] if x == x else float("nan")
 
     def _sort(self):
-        ind = np.argsort(self.fsim)
-        self.sim = np.take(self.sim, ind, 0)
-        self.fsim = np.take(self.fsim, ind, 0)
+        f0, f1 = self.fsim
+        if f1 < f0 or (f0 != f0 and f1 == f1):  # argsort: ascending, stable, NaN last
+            self.sim.reverse()
+            self.fsim.reverse()
 
     # -- one SciPy step, reading the speculative results --------------------------------------
     def advance(self, table):
@@ -93,23 +102,23 @@ class _Start:
                 if fxr < fsim[0]:
                     fxe = self._f(table, self._xe)
                     if fxe < fxr:
-                        sim[-1], fsim[-1] = self._xe, fxe
+                        sim[1], fsim[1] = self._xe, fxe
                     else:
-                        sim[-1], fsim[-1] = self._xr, fxr
+                        sim[1], fsim[1] = self._xr, fxr
                 else:  # fsim[0] <= fxr; with one parameter fsim[-2] is fsim[0], so no plain accept
-                    if fxr < fsim[-2]:
-                        sim[-1], fsim[-1] = self._xr, fxr
+                    if fxr < fsim[0]:
+                        sim[1], fsim[1] = self._xr, fxr
                     else:
-                        if fxr < fsim[-1]:
+                        if fxr < fsim[1]:
                             fxc = self._f(table, self._xc)
                             if fxc <= fxr:
-                                sim[-1], fsim[-1] = self._xc, fxc
+                                sim[1], fsim[1] = self._xc, fxc
                             else:
                                 doshrink = True
                         else:
                             fxcc = self._f(table, self._xcc)
-                            if fxcc < fsim[-1]:
-                                sim[-1], fsim[-1] = self._xcc, fxcc
+                            if fxcc < fsim[1]:
+                                sim[1], fsim[1] = self._xcc, fxcc
                             else:
                                 doshrink = True
                         if doshrink:
@@ -124,14 +133,15 @@ class _Start:
     def _check_done(self):
         if not (self.fcalls < self.maxfun and self.iterations < self.maxiter):
             self.done = True
-        else:
-            with np.errstate(invalid="ignore"):
-                if (np.max(np.abs(self.sim[1:] - self.sim[0])) <= self.xatol
-                        and np.max(np.abs(self.fsim[0] - self.fsim[1:])) <= self.fatol):
-                    self.done = True
+        elif abs(self.sim[1] - self.sim[0]) <= self.xatol and abs(self.fsim[0] - self.fsim[1]) <= self.fatol:
+            self.done = True
 
     def result(self):
-        return self.sim[:1].copy(), float(np.min(self.fsim)), self.iterations, self.fcalls
+        f0, f1 = self.fsim
+        fmin_ = f0 if (f0 <= f1 or f1 != f1) and f0 == f0 else (f1 if f1 == f1 else float("nan"))
+        if f0 != f0 or f1 != f1:  # np.min propagates NaN
+            fmin_ = float("nan")
+        return np.array([self.sim[0]], dtype=np.float64), float(fmin_), self.iterations, self.fcalls
 
 
 def fmin_lockstep(objective_batch, starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None):
@@ -146,10 +156,9 @@ def fmin_lockstep(objective_batch, starts, xtol=1e-4, ftol=1e-4, maxiter=None, m
         active = [run for run in runs if not run.done]
         if not active:
             break
-        wanted = [run.wanted() for run in active]
-        flat = np.array(sorted({float(x) for xs in wanted for x in xs if x == x}), dtype=np.float64)
-        values = np.asarray(objective_batch(flat), dtype=np.float64)
-        table = dict(zip(flat.tolist(), values.tolist()))
+        points = sorted({x for run in active for x in run.wanted() if x == x})
+        values = np.asarray(objective_batch(np.array(points, dtype=np.float64)), dtype=np.float64)
+        table = dict(zip(points, values.tolist()))
         for run in active:
             run.advance(table)
     return [run.result() for run in runs]
