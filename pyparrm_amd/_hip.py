@@ -334,8 +334,10 @@ def to_host_numpy(t) -> np.ndarray:
         host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     except RuntimeError:  # the page-lock limit of the host: fall back to the pageable copy
         return t.cpu().numpy()
-    host.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
+    # a BLOCKING copy: a non-blocking one makes PyTorch's pinned allocator tie the block to the stream
+    # and record an event when the array is finally dropped -- at interpreter exit that lands in a
+    # runtime that may already be gone (seen as an intermittent crash after a green test run)
+    host.copy_(t)
     return host.numpy()
 
 
