@@ -23,3 +23,16 @@ def golden():
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
     return load
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Drain the device and drop what the tests left behind while the HIP runtime is certainly still
+    up: objects that own device or page-locked memory (plans, workspaces, read-back arrays) are then
+    released here and not during interpreter shutdown."""
+    import gc
+
+    gc.collect()
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
