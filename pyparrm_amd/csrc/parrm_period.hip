@@ -288,12 +288,16 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 
+// NW = waves per workgroup: 4 (256 data columns; the Gram row-tiles spread over waves 0-2), or 1 for
+// recordings of <= 64 channels (one wave takes the 64 data columns and all nine Gram tiles: 21 MFMAs
+// per step instead of 60 -- few-channel recordings are the common case in practice).
+template <int NW>
 __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, int64_t ldy, const double *Ws,
                                                               int n_pad, int n_idx, int n_chans, int n_periods,
                                                               int kpc, int nsplit, double *part) {
-    constexpr int KS = 48, D = 4;
+    constexpr int KS = 48, D = 4, NG = NW == 4 ? 1 : 3;  // Gram row-tiles per wave
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = NW == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const int c = lane & 15, sj = lane >> 4;
     const int sl = blockIdx.x, pb = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
     const int ncb = KS / kpc;
@@ -316,14 +320,17 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
     unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
     unsigned vw = static_cast<unsigned>(((u_lo * 4 + sj) * KS + c) * 8);
 
-    d4_t acc[3][4], gacc[3];
+    d4_t acc[3][4], gacc[NG][3];
     double yy[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) {
-        gacc[rt] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[rt][t] = d4_t{0.0, 0.0, 0.0, 0.0};
     }
+#pragma unroll
+    for (int gr = 0; gr < NG; ++gr)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) gacc[gr][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
     double ra[D][3], ry[D][4];
     auto fetch = [&](int d) {
         const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
@@ -356,12 +363,19 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
                 for (int rt = 0; rt < 3; ++rt)
                     acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
             }
-            {   // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
+            if constexpr (NW == 4) {
+                // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
                 // compiler shuttle the Gram accumulators between register files every step)
                 const double aw = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct)
-                    gacc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, a[ct], gacc[ct], 0, 0, 0);
+                    gacc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, a[ct], gacc[0][ct], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int gr = 0; gr < 3; ++gr)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct)
+                        gacc[gr][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gr], a[ct], gacc[gr][ct], 0, 0, 0);
             }
         }
     }
@@ -389,13 +403,17 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
     }
     if (wv < 3) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int r = 16 * wv + sj + 4 * v;
-            const int pc = pb * ncb + r / kpc;
-            if (pc >= n_periods) continue;
-            double *row = block_of(pc) + static_cast<int64_t>(r % kpc) * kNCol + kYCols;
+        for (int gr = 0; gr < NG; ++gr) {
+            const int rt = NW == 4 ? wv : gr;
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) row[16 * ct + c] = gacc[ct][v];
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * rt + sj + 4 * v;
+                const int pc = pb * ncb + r / kpc;
+                if (pc >= n_periods) continue;
+                double *row = block_of(pc) + static_cast<int64_t>(r % kpc) * kNCol + kYCols;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) row[16 * ct + c] = gacc[gr][ct][v];
+            }
         }
     }
     if (sj == 0) {
@@ -744,10 +762,11 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
     // nsplit 4 -> 1524 = 3 rounds of half the length).  Each extra slice costs a 125 KB partial block
     // for fit_reduce_kernel, hence the small per-slice penalty; never below 4 tiles per slice.
     const int64_t max_split = std::max<int64_t>(1, std::min<int64_t>(64, (tiles + 3) / 4));
+    const int64_t resident = n_chans <= 64 ? 1024 : 512;  // one-wave workgroups (<= 64 channels): four per CU
     double best = 1e300;
     g.nsplit = 1;
     for (int64_t ns = 1; ns <= max_split; ++ns) {
-        const int64_t rounds = (groups * g.nz * ns + 511) / 512;
+        const int64_t rounds = (groups * g.nz * ns + resident - 1) / resident;
         const double cost = static_cast<double>(rounds) / static_cast<double>(ns) * (1.0 + 0.004 * ns);
         if (cost < best - 1e-12) {
             best = cost;
@@ -910,8 +929,11 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
                            bw, g.KP, exact_trig, wmat);
     PARRM_HIP_CHECK(hipGetLastError());
     const dim3 grid(g.nsplit, groups, g.nz);
-    if (use_mfma)
-        hipLaunchKernelGGL(fit_accum_mfma_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
+    if (use_mfma && C <= 64)
+        hipLaunchKernelGGL(fit_accum_mfma_kernel<1>, grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
+                           part);
+    else if (use_mfma)
+        hipLaunchKernelGGL(fit_accum_mfma_kernel<4>, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
                            part);
     else
         hipLaunchKernelGGL(fit_accum_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit, part);

@@ -69,6 +69,8 @@ def main():
                       f"phw {phw} {dtype.__name__} shape '{shape}' stretch '{stretch}' kernel {kern}: rel err {err:.3e}")
                 sys.exit(1)
         plan.set_kernel(_hip.KERNEL_AUTO)
+        if case % 10 == 9:
+            print(f"  ... {case + 1} cases, worst so far {worst:.2e}", flush=True)
     print(f"{args.cases} cases ok; worst f64 relative error {worst:.2e}")
 
 

@@ -66,6 +66,8 @@ def main():
                 print(f"FAIL case {case}: C {n_chans} N {n_samples} n_idx {idx.shape[0]} bw {bw} lambda {lam} P {n_per} env {env}: "
                       f"rel err {err:.3e}")
                 sys.exit(1)
+        if case % 5 == 4:
+            print(f"  ... {case + 1} cases, worst so far {worst:.2e}", flush=True)
     print(f"{args.cases} cases ok; worst relative error {worst:.2e}")
 
 
