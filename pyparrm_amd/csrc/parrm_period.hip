@@ -8,8 +8,10 @@
 //                    (G, R, y'y) into the channel-averaged regularised error         (:585-597,:626-632)
 //
 // The regression is a skinny f64 contraction (K <= 47 rows, n <= 25001 samples, C+K columns), bound
-// by FP64 vector FMA + sincos issue, not by HBM: Y (<= 51 MB) stays in L2 / Infinity Cache.
-// No MFMA: FP64 matrix and vector peaks are equal on MI355X (hard part 4).
+// by FP64 arithmetic, not by HBM: Y (<= 51 MB) stays in L2 / Infinity Cache.  It runs on the matrix
+// cores (fit_accum_mfma_kernel, v_mfma_f64_16x16x4_f64: the FP64 matrix and vector peaks are equal on
+// MI355X, but the MFMA form needs far fewer operand fetches and leaves the vector ALU free);
+// fit_accum_kernel is the vector-ALU form for operand layouts the MFMA kernel cannot take.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -428,11 +430,14 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
 }
 
 // red[(p*nz+zb)][e] = sum_s part[(p*nz+zb)][s][e], s ascending (deterministic)
-__global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int nsplit, int64_t elems,
-                                                          double *red) {
+// (data columns beyond the recording's channels are never read by the solvers: skipped)
+__global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int nsplit, int64_t elems, int nz,
+                                                          int n_chans, double *red) {
     const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e >= elems) return;
     const int64_t pz = blockIdx.y;
+    const int col = static_cast<int>(e % kNCol), zb = static_cast<int>(pz % nz);
+    if (col < kYCols && zb * kYCols + col >= n_chans) return;
     const double *src = part + pz * nsplit * elems + e;
     double a = 0.0;
     for (int s = 0; s < nsplit; ++s) a += src[s * elems];
@@ -941,7 +946,7 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
     if (g.nsplit > 1) {
         const dim3 rgrid(static_cast<unsigned>((g.elems + 255) / 256), static_cast<unsigned>(n_periods * g.nz));
         PARRM_REQUIRE(n_periods * g.nz <= 65535, "fit_errors: periods x column blocks too large");
-        hipLaunchKernelGGL(fit_reduce_kernel, rgrid, dim3(256), 0, s, part, g.nsplit, g.elems, red);
+        hipLaunchKernelGGL(fit_reduce_kernel, rgrid, dim3(256), 0, s, part, g.nsplit, g.elems, g.nz, C, red);
         PARRM_HIP_CHECK(hipGetLastError());
     }
     const int K = 2 * bw + 1;
