@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kMaxRingLog2F64 = 14;  // 16384 * 8 B = 128 KiB of the 160 KiB LDS
 constexpr int kMaxRowsPerFill = 8;
-constexpr int kMaxBlock = 256;
+constexpr int kMaxBlock = 512;
 
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) filter_gather_kernel(FilterArgs a) {
@@ -165,11 +165,6 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
 
 namespace {
 
-int next_pow2_log2(int64_t v) {
-    int l = 0;
-    while ((int64_t{1} << l) < v) ++l;
-    return l;
-}
 
 constexpr int kDeltaSizes[] = {8, 16, 24, 32, 48, 64, 96, 128};
 
@@ -177,6 +172,12 @@ int padded_delta(int64_t n) {  // smallest compiled unroll >= n, 0 if none
     for (int d : kDeltaSizes)
         if (n <= d) return d;
     return 0;
+}
+
+int next_pow2_log2(int64_t v) {
+    int l = 0;
+    while ((int64_t{1} << l) < v) ++l;
+    return l;
 }
 
 // Choose the recurrence stride: minimise (LDS reads per output row) / (lane utilisation).
@@ -196,11 +197,29 @@ void choose_stride(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan
         const int64_t nd = 2 * (static_cast<int64_t>(taps_at.size()) - both);
         const int pad = padded_delta(nd);
         if (pad == 0) continue;
+        // Measured on MI355X (256 x 10 M f64, periods 1.3 ... 48 samples, strides 39 ... 507): the
+        // kernel is latency-bound, time ~ (delta taps + ~26 instructions of per-row overhead) /
+        // (waves resident per CU, saturating at about 8).  Residency: one power-of-two ring per
+        // workgroup (LDS), ~40 + 3*pad VGPRs per lane (tap offsets and weights live in registers).
         const int64_t block = (q + 63) / 64 * 64;
-        const double cost = static_cast<double>(pad + 6) * static_cast<double>(block) / static_cast<double>(q);
-        if (cost < best_cost - 1e-12 || (std::fabs(cost - best_cost) <= 1e-12 && q > best_q)) {
+        const int64_t ring_bytes = (int64_t{1} << next_pow2_log2(2 * hw + 3 * q)) * 8 + 2048;
+        const int64_t by_lds = std::max<int64_t>(1, (160 * 1024) / ring_bytes);
+        const int64_t by_regs = std::max<int64_t>(1, 512 / (40 + 3 * pad)) * 4;  // waves per CU
+        const int64_t waves = std::min<int64_t>(std::min<int64_t>(by_lds, 8) * (block / 64), by_regs);
+        const double cost = static_cast<double>(pad + 26) / static_cast<double>(std::min<int64_t>(waves, 8)) *
+                            (0.75 + 0.25 * static_cast<double>(block) / static_cast<double>(q)) *
+                            (1.0 + static_cast<double>(block) / 4096.0);  // past saturation smaller workgroups ran faster
+        if (cost < best_cost - 1e-12) {  // ties: the smaller stride (measured: equal or better)
             best_cost = cost;
             best_q = q;
+        }
+    }
+    if (const char *env = getenv("PARRM_STRIDE_Q")) {  // tuning knob: force the stride (must have a compiled unroll)
+        const int64_t fq = atoll(env);
+        if (fq >= 32 && fq <= kMaxBlock && 2 * hw + 3 * fq <= (int64_t{1} << kMaxRingLog2F64)) {
+            int64_t both = 0;
+            for (const int64_t w : taps_at) both += tap_at(w + fq);
+            if (padded_delta(2 * (static_cast<int64_t>(taps_at.size()) - both)) != 0) best_q = fq;
         }
     }
     p->q = best_q;
