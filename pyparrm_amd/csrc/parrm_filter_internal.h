@@ -69,7 +69,8 @@ struct PhaseGeom {
     int32_t d_pad;        // padded length of the +1 and of the -1 delta lists
     int32_t n_runs;       // full-tap runs for the per-stretch initialisation
     int32_t debug;        // ablation bits for profiling builds (PARRM_DEBUG_FLAGS); 0 in production
-    const int32_t *tab;   // [4*d_pad] plus_a', plus_b, minus_a', minus_b ; then [3*n_runs] (a', b_lo, b_hi)
+    int32_t wrap;         // 1: residues b in [0, q) with per-lane wrap to the previous row (guard == 0)
+    const int32_t *tab;   // [M][2*d_pad] tap offsets per table row; [3*n_runs] (a', b_lo, b_hi); wrap: [2*d_pad] b
 };
 
 }  // namespace parrm_filter

@@ -124,7 +124,13 @@ __device__ inline void tap_pair(unsigned ad_p, unsigned ad_m, TI (&v)[4]) {
     }
 }
 
-template <typename TI, typename TO, int DP, int R>
+// WRAP: the general-residue form for SHORT artefact periods.  There the taps do not sit near the
+// multiples of any stride q but at several residues of it, so a delta tap u = a*q + b is split with
+// b in [0, q) and lane r reads residue r - b of row m - a when r >= b, and residue r - b + q of row
+// m - a - 1 when r < b: the same address plus the constant (q*RS - 1) elements.  Which taps wrap is a
+// per-lane bit mask fixed for the kernel; every column carries one extra slot in front (a copy of
+// the last slot) so that "one slot earlier" never leaves the column.  No mirrored residues (B = 0).
+template <typename TI, typename TO, int DP, int R, bool WRAP>
 __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseGeom p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int kEl = static_cast<int>(sizeof(TI));
@@ -158,9 +164,11 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 
     // Cell (rho, row) holds sample s0 + row*q + rho for every rho in [-B, q+B): the B-wide halos are
     // ordinary columns owned by the otherwise idle lanes of the last wave.  slot(row) = (row+a_hi) mod M.
-    const int fill_base = (rho + B) * RS * kEl;                  // byte offset of (rho, slot 0)
+    constexpr int kFront = WRAP ? 1 : 0;                         // slots in front of slot 0
+    const int fill_base = ((rho + B) * RS + kFront) * kEl;       // byte offset of (rho, slot 0)
     // (idle lanes mirror the last residue: same address as a lane of their own half -> broadcast, no bank conflict)
-    const int lane_base = ((active ? r : q - 1) + B) * RS * kEl;  // byte offset of (r, slot 0)
+    const int r_eff = active ? r : q - 1;
+    const int lane_base = ((r_eff + B) * RS + kFront) * kEl;      // byte offset of (r, slot 0)
     // Rows whose whole span (halos included) is addressable take a wave-uniform fast path: scalar
     // base pointer + per-lane unsigned offset (no per-lane bounds tests).  Computed once per stretch.
     auto floor_div = [](int64_t x, int64_t d) -> int64_t { return x >= 0 ? x / d : -((-x + d - 1) / d); };
@@ -182,6 +190,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl * kEl);
         *cell = v;
         if (sl < R - 1) cell[M] = v;
+        if (WRAP && sl == M - 1) cell[-M] = v;  // the slot in front of slot 0
     };
 
     // prologue: rows [-a_hi, NGR - a_lo) of xz, eight loads per lane in flight
@@ -209,6 +218,17 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         pre_a[i] = (filler && NGR < rows_total) ? load_row(NGR - a_lo + g * R + i) : TI(0);
     __syncthreads();
 
+    // wrap: a tap with residue offset b > r reads (residue r - b + q, one row earlier)
+    const int wrap_corr = (q * RS - 1) * kEl;
+    unsigned wrap_p = 0, wrap_m = 0;  // bit t: this lane wraps +1 tap t / -1 tap t
+    if constexpr (WRAP) {
+        const int32_t *bl = runs + 3 * p.n_runs;
+        for (int t = 0; t < DP; ++t) {
+            wrap_p |= (r_eff < bl[t] ? 1u : 0u) << t;
+            wrap_m |= (r_eff < bl[DP + t] ? 1u : 0u) << t;
+        }
+    }
+
     // S at row 0 for this residue: full evaluation, once per stretch (every group, redundantly)
     double S = 0.0;
     if (active) {
@@ -217,12 +237,18 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             const int ra = runs[3 * k], b_lo = runs[3 * k + 1], b_hi = runs[3 * k + 2];
             const int sl = (a_hi - a_lo - ra) % M;  // slot(0 - a), a = ra + a_lo
             const unsigned char *base = lds_raw + lane_base + sl * kEl;
-            int b = b_lo;
-            for (; b + 1 <= b_hi; b += 2) {
-                s_a += static_cast<double>(*reinterpret_cast<const TI *>(base - b * RS * kEl));
-                s_b += static_cast<double>(*reinterpret_cast<const TI *>(base - (b + 1) * RS * kEl));
+            if constexpr (WRAP) {
+                for (int b = b_lo; b <= b_hi; ++b)
+                    s_a += static_cast<double>(
+                        *reinterpret_cast<const TI *>(base - b * RS * kEl + (r < b ? wrap_corr : 0)));
+            } else {
+                int b = b_lo;
+                for (; b + 1 <= b_hi; b += 2) {
+                    s_a += static_cast<double>(*reinterpret_cast<const TI *>(base - b * RS * kEl));
+                    s_b += static_cast<double>(*reinterpret_cast<const TI *>(base - (b + 1) * RS * kEl));
+                }
+                if (b <= b_hi) s_a += static_cast<double>(*reinterpret_cast<const TI *>(base - b * RS * kEl));
             }
-            if (b <= b_hi) s_a += static_cast<double>(*reinterpret_cast<const TI *>(base - b * RS * kEl));
         }
         S = s_a + s_b;
     }
@@ -270,8 +296,13 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             // one being accumulated, one counted wait per four reads
             TI v[2][4];
             auto issue = [&](int u, TI (&b)[4], auto wait) {
-                tap_pair<TI, decltype(wait)::value>(lds0 + (static_cast<unsigned>(e[u]) << kElLog2),
-                                                    lds0 + (static_cast<unsigned>(e[DP + u]) << kElLog2), b);
+                unsigned ap = lds0 + (static_cast<unsigned>(e[u]) << kElLog2);
+                unsigned am = lds0 + (static_cast<unsigned>(e[DP + u]) << kElLog2);
+                if constexpr (WRAP) {
+                    ap += __builtin_amdgcn_ubfe(wrap_p, u, 1) * static_cast<unsigned>(wrap_corr);
+                    am += __builtin_amdgcn_ubfe(wrap_m, u, 1) * static_cast<unsigned>(wrap_corr);
+                }
+                tap_pair<TI, decltype(wait)::value>(ap, am, b);
             };
             auto accumulate = [&](int u, TI (&b)[4]) {
                 if (u == 0) {
@@ -303,7 +334,10 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             constexpr int W3 = 3 * R;
             TI v[4][R];
             auto addr = [&](int j) -> unsigned {  // j even: +1 tap j/2, j odd: -1 tap j/2
-                return lds0 + (static_cast<unsigned>(e[(j & 1) * DP + (j >> 1)]) << kElLog2);
+                unsigned ad = lds0 + (static_cast<unsigned>(e[(j & 1) * DP + (j >> 1)]) << kElLog2);
+                if constexpr (WRAP)
+                    ad += __builtin_amdgcn_ubfe((j & 1) ? wrap_m : wrap_p, j >> 1, 1) * static_cast<unsigned>(wrap_corr);
+                return ad;
             };
             auto accumulate = [&](int j, TI (&b)[R]) {
 #pragma unroll
@@ -486,7 +520,8 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         xchg[(par * NG + g) * QP + r] = tot;
         // 3. publish
         if (filler) {
-            if (sl_fill >= R - 1 && sl_fill + R <= M) {  // no wrap, no mirrored head: R adjacent cells
+            // no wrap, no mirrored head (nor, in the wrap form, the mirrored last slot): R adjacent cells
+            if (sl_fill >= R - 1 && sl_fill + R <= M - kFront) {
                 TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl_fill * kEl);
 #pragma unroll
                 for (int i = 0; i < R; ++i) cell[i] = pub[i];
@@ -551,8 +586,12 @@ int pad_half(int64_t n) {
 struct Split {
     int a, b;
 };
-inline Split split(int64_t u, int64_t q) {
+inline Split split(int64_t u, int64_t q) {  // nearest multiple: b in (-q/2, q/2]
     const int64_t a = static_cast<int64_t>(std::floor(static_cast<double>(u) / static_cast<double>(q) + 0.5));
+    return {static_cast<int>(a), static_cast<int>(u - a * q)};
+}
+inline Split split_floor(int64_t u, int64_t q) {  // wrap form: b in [0, q)
+    const int64_t a = u >= 0 ? u / q : -((-u + q - 1) / q);
     return {static_cast<int>(a), static_cast<int>(u - a * q)};
 }
 
@@ -597,10 +636,33 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         }
     }
     plan->phase = PhaseGeom{};
+    // Short periods: no stride keeps every tap within kMaxGuard residues of its multiples.  The wrap
+    // form (b in [0, q), per-lane wrap to the previous row) takes any stride whose delta list is short.
+    bool wrap = false;
+    if (best_q == 0) {
+        for (int64_t q = 64; q <= 512; ++q) {
+            int64_t both = 0;
+            for (const int64_t w : taps_at) both += tap_at(w + q);
+            const int64_t nd = 2 * (static_cast<int64_t>(taps_at.size()) - both);
+            if (nd == 0) continue;
+            const int dp = pad_half(nd / 2);
+            if (dp == 0) continue;
+            const int64_t qp = (q + 63) / 64 * 64;
+            // two more vector instructions per tap than the guarded form (wrap bit, multiply-add)
+            const double cost = (2.0 * dp * 2.0 + 20.0) * static_cast<double>(qp) / static_cast<double>(q);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_q = q;
+            }
+        }
+        wrap = best_q != 0;
+    }
     if (best_q == 0) return;
     const int64_t q = best_q;
+    auto split = [&](int64_t u, int64_t qq) -> Split { return wrap ? split_floor(u, qq) : parrm_filter::split(u, qq); };
     PhaseGeom g{};
     g.q = static_cast<int32_t>(q);
+    g.wrap = wrap ? 1 : 0;
     std::vector<Split> plus, minus;
     int a_lo = 0, a_hi = 0, guard = 0;
     auto note = [&](const Split &s) {
@@ -632,13 +694,13 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         runs.push_back(split(v, q).b);
         u = v + 1;
     }
-    g.guard = std::max(guard, 1);
+    g.guard = wrap ? 0 : std::max(guard, 1);
     g.d_pad = pad_half(static_cast<int64_t>(plus.size()));
     g.n_runs = static_cast<int32_t>(runs.size() / 3);
     // the 2*guard halo columns are owned by the idle lanes of the last wave of each row group
     g.qp = static_cast<int32_t>((q + 2 * g.guard + 63) / 64 * 64);
     g.a_lo = std::min(a_lo, 0);
-    g.a_hi = std::max(a_hi, 0);
+    g.a_hi = std::max(a_hi, 0) + (wrap ? 1 : 0);  // wrapped lanes reach one row further back
     // (groups, rows per thread), best first.  Measured on 256 x 10M f64, q = 169: (4,2) 10.2 ms,
     // (2,3) 10.3, (2,4) 10.4, (2,2) 11.2, (3,2) 11.5, (3,3) 11.9 -- 24 waves per CU (two 12-wave
     // workgroups, three waves per SIMD each) hide more latency than the extra instructions of R = 2 cost.
@@ -661,7 +723,7 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
             // rows resident at once: the taps' reach around the NG*R rows being computed, plus the
             // NG*R rows published meanwhile
             g.m_slots = 2 * ngr + (g.a_hi - g.a_lo);
-            g.rs = g.m_slots + g.rows - 1;
+            g.rs = g.m_slots + g.rows - 1 + (wrap ? 1 : 0);  // + mirrored head, + the slot in front (wrap)
             if ((g.rs & 1) == 0) ++g.rs;
             if (g.n_groups * g.qp > 1024) continue;
             if (lds_bytes(g, sizeof(double)) <= (pass == 0 ? kLdsTwoBlocks : kLdsOneBlock)) {
@@ -691,16 +753,23 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         table->push_back(runs[k + 1]);
         table->push_back(runs[k + 2]);
     }
+    if (wrap) {  // residue offsets of the delta taps, for the per-lane wrap masks
+        for (int sign = 0; sign < 2; ++sign)
+            for (int t = 0; t < g.d_pad; ++t) table->push_back(pick(sign == 0 ? plus : minus, t).b);
+    }
     plan->phase = g;
 }
 
 template <typename TI, typename TO, int DP>
 static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs a, PhaseGeom g, hipStream_t stream) {
     void (*kern)(FilterArgs, PhaseGeom) = nullptr;
-    switch (g.rows) {
-        case 2: kern = filter_phase_kernel<TI, TO, DP, 2>; break;
-        case 3: kern = filter_phase_kernel<TI, TO, DP, 3>; break;
-        case 4: kern = filter_phase_kernel<TI, TO, DP, 4>; break;
+    switch (g.rows * 2 + (g.wrap ? 1 : 0)) {
+        case 4: kern = filter_phase_kernel<TI, TO, DP, 2, false>; break;
+        case 5: kern = filter_phase_kernel<TI, TO, DP, 2, true>; break;
+        case 6: kern = filter_phase_kernel<TI, TO, DP, 3, false>; break;
+        case 7: kern = filter_phase_kernel<TI, TO, DP, 3, true>; break;
+        case 8: kern = filter_phase_kernel<TI, TO, DP, 4, false>; break;
+        case 9: kern = filter_phase_kernel<TI, TO, DP, 4, true>; break;
         default: parrm::set_error("filter: unsupported rows-per-thread %d", g.rows); return PARRM_ERR_INVALID;
     }
     const int ngr = g.n_groups * g.rows;
