@@ -640,7 +640,10 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     // form (b in [0, q), per-lane wrap to the previous row) takes any stride whose delta list is short.
     bool wrap = false;
     if (best_q == 0) {
+        const char *force = getenv("PARRM_PHASE_Q");  // tuning knob: the wrap form's stride
+        const int64_t fq = force ? atoll(force) : 0;
         for (int64_t q = 64; q <= 512; ++q) {
+            if (fq && q != fq) continue;
             int64_t both = 0;
             for (const int64_t w : taps_at) both += tap_at(w + q);
             const int64_t nd = 2 * (static_cast<int64_t>(taps_at.size()) - both);
@@ -705,6 +708,15 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     // (2,3) 10.3, (2,4) 10.4, (2,2) 11.2, (3,2) 11.5, (3,3) 11.9 -- 24 waves per CU (two 12-wave
     // workgroups, three waves per SIMD each) hide more latency than the extra instructions of R = 2 cost.
     int kShapes[8][2] = {{4, 2}, {2, 4}, {2, 3}, {2, 2}, {3, 2}, {1, 4}, {1, 3}, {1, 2}};
+    if (wrap) {
+        // wrap form: delta lists are short and strides often large; two-row shapes first (measured:
+        // q = 500 as (2,4) 20 ms, as (1,2) 14 ms; q = 201 as (2,4) 20 ms, q = 197 as (2,3) 13.6 ms)
+        const int order[8][2] = {{4, 2}, {2, 2}, {3, 2}, {1, 2}, {2, 3}, {1, 3}, {2, 4}, {1, 4}};
+        for (int i = 0; i < 8; ++i) {
+            kShapes[i][0] = order[i][0];
+            kShapes[i][1] = order[i][1];
+        }
+    }
     if (const char *env = getenv("PARRM_PHASE_SHAPE")) {  // tuning knob: "NG,R" tried first
         int ng = 0, rr = 0;
         if (sscanf(env, "%d,%d", &ng, &rr) == 2 && ng >= 1 && ng <= 5 && rr >= 2 && rr <= 4) {
