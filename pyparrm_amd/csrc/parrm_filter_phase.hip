@@ -636,6 +636,10 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         }
     }
     plan->phase = PhaseGeom{};
+    if (getenv("PARRM_PHASE_FORCE_WRAP")) {  // tuning knob: wrap form even where the guarded one fits
+        best_q = 0;
+        best_cost = 1e300;
+    }
     // Short periods: no stride keeps every tap within kMaxGuard residues of its multiples.  The wrap
     // form (b in [0, q), per-lane wrap to the previous row) takes any stride whose delta list is short.
     bool wrap = false;
