@@ -646,7 +646,7 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     if (best_q == 0) {
         const char *force = getenv("PARRM_PHASE_Q");  // tuning knob: the wrap form's stride
         const int64_t fq = force ? atoll(force) : 0;
-        for (int64_t q = 64; q <= 512; ++q) {
+        for (int64_t q = 32; q <= 512; ++q) {  // (strides below one wave: integer periods, whose delta list grows with q)
             if (fq && q != fq) continue;
             int64_t both = 0;
             for (const int64_t w : taps_at) both += tap_at(w + q);
