@@ -132,6 +132,21 @@ def test_filter_shapes_and_taps(case, shape):
         _assert_filter_close(y, ref, rtol=1e-10)
 
 
+@pytest.mark.parametrize("period", [1.3311148014466094, 1.9230769, 2.0, 7.6923, 7.742402205597892, 13.0, 47.9])
+def test_short_periods_take_the_phase_kernel(period):
+    # the wrap form of the phase-major kernel: taps at several residues of the stride, per-lane wrap
+    # to the previous row (parity of every variant is in test_filter_shapes_and_taps / fuzz_filter.py)
+    n = 300_000
+    hw = orc.default_filter_half_width(n, period, 0, period / 50)
+    taps = orc.generate_filter(period, hw, 0, "both", None)
+    plan = _hip.FilterPlan(taps)
+    info = plan.info
+    assert info.phase_groups > 0 and info.phase_guard == 0 and info.kernel == _hip.KERNEL_PHASE
+    x = synth_recording(2, n, 22000, 130, seed=21)
+    y = _run_filter(plan, x, _hip.KERNEL_AUTO)
+    _assert_filter_close(y, orc.filter_data_direct(x, taps))
+
+
 def test_filter_strided_rows_and_auto_kernel():
     filt = orc.generate_filter(169.23584615384616, 2372, 0, "both", None)
     rng = np.random.default_rng(5)
