@@ -648,10 +648,13 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
     }
     // Short periods: no stride keeps every tap within kMaxGuard residues of its multiples.  The wrap
     // form (b in [0, q), per-lane wrap to the previous row) takes any stride whose delta list is short.
+    // Both searches run; the cheaper estimate wins (the guarded form where it exists with a short delta
+    // list, e.g. the 22 kHz / 130 Hz comb; the wrap form when the guarded delta list is long).
     bool wrap = false;
-    if (best_q == 0) {
+    {
         const char *force = getenv("PARRM_PHASE_Q");  // tuning knob: the wrap form's stride
         const int64_t fq = force ? atoll(force) : 0;
+        if (fq) best_cost = 1e300;
         for (int64_t q = 32; q <= 512; ++q) {  // (strides below one wave: integer periods, whose delta list grows with q)
             if (fq && q != fq) continue;
             int64_t both = 0;
@@ -666,9 +669,9 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
             if (cost < best_cost) {
                 best_cost = cost;
                 best_q = q;
+                wrap = true;
             }
         }
-        wrap = best_q != 0;
     }
     if (best_q == 0) return;
     const int64_t q = best_q;
