@@ -200,9 +200,9 @@ def test_filter_interior_loop_is_bitwise_the_general_loop(monkeypatch, shape, dt
                          rtol=FILTER_RTOL if dtype == np.float64 else 1e-5)
 
 
-def test_filter_window_and_host_streaming():
-    filt = orc.generate_filter(169.23584615384616, 2372, 3, "both", None)
-    hw = 2372
+@pytest.mark.parametrize("period,hw", [(169.23584615384616, 2372), (7.742402205597892, 2477), (1.9230769, 1250)])
+def test_filter_window_and_host_streaming(period, hw):
+    filt = orc.generate_filter(period, hw, 3, "both", None)
     x = synth_recording(3, 60000, 22000, 130, seed=4)
     plan = _hip.FilterPlan(filt)
     whole = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
