@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PARRM_HIP_ABI_VERSION 1
+#define PARRM_HIP_ABI_VERSION 2
 
 #define PARRM_OK 0
 #define PARRM_ERR_INVALID 1   /* bad argument (NULL, negative size, unsupported dtype...) */
@@ -50,6 +50,12 @@ int parrm_hip_abi_version(void);
 const char *parrm_hip_last_error(void);
 /* number of visible HIP devices (0 and PARRM_OK when there is none) */
 int parrm_hip_device_count(int *count);
+/* Release what the library keeps for the life of the process (the page-locked hand-off blocks of
+ * parrm_fit_errors_host).  Call it once no other call is in flight and while the HIP runtime is
+ * still up -- e.g. from the host language's exit hook, not from a static destructor.  Everything is
+ * re-created on demand if the library is used again afterwards.  Plans, workspaces and streams
+ * belong to the caller and are not touched. */
+int parrm_hip_shutdown(void);
 
 /* ------------------------------------------------------------------------------------
  * filter_data  (parrm.py:835-875; arithmetic at :861-869)
@@ -60,7 +66,8 @@ int parrm_hip_device_count(int *count);
  * A plan is built from the reference's dense filter array `PARRM._filter`
  * (parrm.py:803-833: 1 at the centre, -1/S on taps, 0 elsewhere; length 2*hw+1).  Building
  * the plan derives the tap runs, picks the recurrence stride q and uploads the tables to
- * the current device (synchronous).  A plan is bound to the device it was created on.
+ * the current device (synchronous).  A plan is bound to the device it was created on:
+ * parrm_filter_apply* fail with PARRM_ERR_INVALID when another device is current.
  * ------------------------------------------------------------------------------------ */
 typedef struct parrm_filter_plan parrm_filter_plan;
 

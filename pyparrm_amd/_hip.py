@@ -7,6 +7,7 @@ every compute entry point raises.  PyTorch is used only to own device memory and
 
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import threading
@@ -23,6 +24,7 @@ SYMBOLS = (
     "parrm_hip_abi_version",
     "parrm_hip_last_error",
     "parrm_hip_device_count",
+    "parrm_hip_shutdown",
     "parrm_filter_plan_create",
     "parrm_filter_plan_destroy",
     "parrm_filter_plan_query",
@@ -106,6 +108,8 @@ def lib() -> C.CDLL:
         L.parrm_hip_last_error.argtypes = []
         L.parrm_hip_device_count.restype = i32
         L.parrm_hip_device_count.argtypes = [C.POINTER(i32)]
+        L.parrm_hip_shutdown.restype = i32
+        L.parrm_hip_shutdown.argtypes = []
         L.parrm_filter_plan_create.restype = i32
         L.parrm_filter_plan_create.argtypes = [vp, i64, C.POINTER(vp)]
         L.parrm_filter_plan_destroy.restype = i32
@@ -136,10 +140,18 @@ def lib() -> C.CDLL:
         L.parrm_fit_errors.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
         L.parrm_fit_errors_host.restype = i32
         L.parrm_fit_errors_host.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
-        if L.parrm_hip_abi_version() != 1:
-            raise HipLibraryError("libparrm_hip.so has an unexpected ABI version")
+        if L.parrm_hip_abi_version() != 2:
+            raise HipLibraryError("libparrm_hip.so has an unexpected ABI version (rebuild it: make -C pyparrm_amd/csrc)")
         _lib = L
+        # library-lifetime resources go back while the HIP runtime is certainly up: atexit hooks run at
+        # the start of interpreter shutdown, before any module (torch, this one) is torn down
+        atexit.register(_shutdown)
     return _lib
+
+
+def _shutdown() -> None:
+    if _lib is not None:
+        _lib.parrm_hip_shutdown()
 
 
 def check(rc: int, what: str = "") -> None:
@@ -217,16 +229,33 @@ def _check_rows(t, name: str) -> None:
 class FilterPlan:
     """Device-side plan for one PARRM filter (``parrm_filter_plan_*``)."""
 
-    def __init__(self, filt: np.ndarray):
+    def __init__(self, filt: np.ndarray, device: int | None = None):
+        """``device``: index of the HIP device whose memory holds the plan's tables (default: the
+        current device).  A plan only serves recordings on that device."""
         self._h = C.c_void_p(None)
-        require_gpu()
+        torch = require_gpu()
         f = np.ascontiguousarray(filt, dtype=np.float64)
         if f.ndim != 1:
             raise ValueError("filter must be 1-D")
-        check(
-            lib().parrm_filter_plan_create(f.ctypes.data_as(C.c_void_p), f.shape[0], C.byref(self._h)),
-            "parrm_filter_plan_create",
-        )
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        with torch.cuda.device(self.device):
+            check(
+                lib().parrm_filter_plan_create(f.ctypes.data_as(C.c_void_p), f.shape[0], C.byref(self._h)),
+                "parrm_filter_plan_create",
+            )
+
+    def _refuse_copy(self, *_args):
+        raise TypeError("a FilterPlan owns device memory and cannot be copied or pickled; build one "
+                        "from the filter array")
+
+    __copy__ = __deepcopy__ = __reduce__ = _refuse_copy
+
+    def _check_device(self, t) -> None:
+        if t.device.index != self.device:
+            raise ValueError(
+                f"this FilterPlan lives on cuda:{self.device} but the recording is on {t.device}; "
+                "build a plan for that device"
+            )
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -246,9 +275,11 @@ class FilterPlan:
         """y = filter(x) for a device-resident recording ``x[C, N]`` (f32/f64)."""
         torch = require_gpu()
         _check_rows(x, "x")
+        self._check_device(x)
         if out is None:
             out = torch.empty(x.shape, dtype=out_dtype or torch.float64, device=x.device)
         _check_rows(out, "out")
+        self._check_device(out)
         if out.shape != x.shape:
             raise ValueError("`out` must have the shape of `x`")
         n_chans, n_samples = x.shape
@@ -278,8 +309,10 @@ class FilterPlan:
         ``x[C, buf_len]`` holds samples [buf_first, buf_first+buf_len)."""
         torch = require_gpu()
         _check_rows(x, "x")
+        self._check_device(x)
         if out is None:
             out = torch.empty((x.shape[0], out_len), dtype=torch.float64, device=x.device)
+        self._check_device(out)
         with torch.cuda.device(x.device):
             check(
                 lib().parrm_filter_apply_window(
@@ -308,6 +341,12 @@ class FilterPlan:
                 raise ValueError("`out` must be a C-contiguous float32/float64 array of the input's shape")
         code_x = F64 if x.dtype == np.float64 else F32
         code_y = F64 if y.dtype == np.float64 else F32
+        torch = require_gpu()
+        with torch.cuda.device(self.device):
+            self._filter_host(x, code_x, y, code_y, chunk_samples)
+        return y
+
+    def _filter_host(self, x, code_x, y, code_y, chunk_samples):
         check(
             lib().parrm_filter_host(
                 self._h, x.ctypes.data_as(C.c_void_p), code_x, y.ctypes.data_as(C.c_void_p), code_y,

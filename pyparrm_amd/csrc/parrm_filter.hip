@@ -449,6 +449,12 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
     PARRM_REQUIRE(buf_first <= need_lo && buf_first + buf_len >= need_hi,
                   "filter_apply: window [%lld,%lld) does not cover the halo [%lld,%lld)", (long long)buf_first,
                   (long long)(buf_first + buf_len), (long long)need_lo, (long long)need_hi);
+    // the plan's tables are a hipMalloc on the device it was created on: a launch from another device
+    // would dereference that device's memory without peer access
+    int current = -1;
+    PARRM_HIP_CHECK(hipGetDevice(&current));
+    PARRM_REQUIRE(current == plan->device, "filter_apply: the plan was built on device %d but device %d is current",
+                  plan->device, current);
 
     FilterArgs a{};
     a.x = d_x;

@@ -14,6 +14,7 @@
 // fit_accum_kernel is the vector-ALU form for operand layouts the MFMA kernel cannot take.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -808,15 +809,14 @@ struct HostStage {
     double *d = nullptr;                   // the same block through the device's mapping
     int device = -1;
     unsigned long long seq = 0;
-    // No destructor: thread-local destructors of the main thread run during process exit, when the
-    // HIP runtime may already be gone (hipHostFree then faults -- seen as an intermittent crash after
-    // a green test run).  The 64 KB block is reclaimed with the process.
+    void release() {
+        if (h) (void)hipHostFree(h);
+        h = d = nullptr;
+        device = -1;
+    }
     bool ready(int dev) {
         if (h && device == dev) return true;
-        if (h) {
-            (void)hipHostFree(h);
-            h = nullptr;
-        }
+        release();
         void *p = nullptr;
         if (hipHostMalloc(&p, (2 * kCap + 8) * sizeof(double), hipHostMallocMapped) != hipSuccess) return false;
         void *dp = nullptr;
@@ -831,7 +831,32 @@ struct HostStage {
         return true;
     }
 };
-thread_local HostStage g_stage;
+
+// Ownership of the hand-off blocks.  A block lives as long as the thread that uses it may call in
+// again, i.e. for the process: it is owned by this registry (one heap object per calling thread, found
+// through a thread_local POINTER -- a trivially destructible thread_local, so nothing of ours runs in
+// the thread-exit / process-exit destructor phase) and released by parrm_hip_shutdown(), which the
+// host binding calls while the HIP runtime is certainly still up (Python: an atexit hook, i.e. before
+// interpreter and library teardown).  Round 1 first freed the block from a thread_local destructor and
+// then leaked it; see DESIGN.md "Teardown".
+struct StageRegistry {
+    std::mutex mu;
+    std::vector<HostStage *> all;
+};
+StageRegistry &registry() {
+    static StageRegistry *r = new StageRegistry();  // never destroyed: no static-destructor ordering to get wrong
+    return *r;
+}
+thread_local HostStage *t_stage = nullptr;
+HostStage &thread_stage() {
+    if (!t_stage) {
+        t_stage = new HostStage();
+        StageRegistry &r = registry();
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.all.push_back(t_stage);
+    }
+    return *t_stage;
+}
 
 }  // namespace
 
@@ -987,8 +1012,8 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
     double *d_err = d_per + n_periods;
     int dev = 0;
     PARRM_HIP_CHECK(hipGetDevice(&dev));
-    if (n_periods <= HostStage::kCap && !getenv("PARRM_FIT_COPY_PATH") && g_stage.ready(dev)) {
-        HostStage &st = g_stage;
+    if (n_periods <= HostStage::kCap && !getenv("PARRM_FIT_COPY_PATH") && thread_stage().ready(dev)) {
+        HostStage &st = thread_stage();
         // (the periods still go through a device copy: every workgroup of the trig kernel reads them,
         // which would be one uncached PCIe read per wave from mapped host memory)
         PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1025,6 +1050,15 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
     if (rc != PARRM_OK) return rc;
     PARRM_HIP_CHECK(hipMemcpyAsync(h_err, d_err, n_periods * sizeof(double), hipMemcpyDeviceToHost, s));
     PARRM_HIP_CHECK(hipStreamSynchronize(s));
+    return PARRM_OK;
+}
+
+int parrm_hip_shutdown(void) {
+    // No call of this library may be in flight on another thread.  Streams the caller passed in are the
+    // caller's; what is released here is what the library allocated for the life of the process.
+    StageRegistry &r = registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    for (HostStage *st : r.all) st->release();  // hipHostFree waits for the device to be done with the block
     return PARRM_OK;
 }
 

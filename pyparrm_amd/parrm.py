@@ -14,12 +14,20 @@ reference tests pin, ``tests/test_parrm.py:112-330``), same call-order state mac
 * ``filter_data``  -> device: closed-form phase-neighbour stencil (``parrm_filter_apply``).
 
 There is no CPU fallback: without the HIP library and a GPU, ``find_period`` / ``filter_data``
-raise.  Extension over the reference (additive): ``data`` may be a 2-D CUDA ``torch.Tensor``
-(results then stay on the device).
+raise.  Extensions over the reference (additive): ``data`` may be a 2-D CUDA ``torch.Tensor``
+(results then stay on the device); ``PARRM.cache_on_device`` (below).
+
+Host recordings are re-read on every ``find_period()`` / ``filter_data()`` call, exactly like the
+reference (which reads ``self._data`` each time, parrm.py:274, :861): an in-place edit of the array
+between two calls is picked up.  Within one call the device copy is shared by all stages.  Setting
+``parrm.cache_on_device = True`` keeps the copy between calls (one upload for
+``find_period`` + ``filter_data``; what an interactive explorer wants) -- the caller then promises
+not to modify the array in place, or calls :meth:`PARRM.release_device_cache` after doing so.
 """
 
 from __future__ import annotations
 
+import copy
 from multiprocessing import cpu_count
 
 import numpy as np
@@ -89,15 +97,61 @@ class PARRM:
     _filter_direction = None
     _period_half_width = None
 
+    #: keep the device copy of a host recording between calls (see the module docstring)
+    cache_on_device = False
+
+    # device-side state: rebuilt lazily, never copied or pickled (``__deepcopy__`` / ``__getstate__``)
+    _DEVICE_STATE = ("_d_data", "_d_data_src", "_d_scale", "_plans", "_last_plan", "_in_call")
+
     # ------------------------------------------------------------------ construction (a1)
     def __init__(self, data, sampling_freq, artefact_freq, verbose=True) -> None:
         self._check_init_inputs(data, sampling_freq, artefact_freq, verbose)
         self._n_chans, self._n_samples = (int(s) for s in self._data.shape)
+        self._reset_device_state()
+        self._trace = None
+
+    def _reset_device_state(self) -> None:
         self._d_data = None  # device copy of a host recording (lazy)
         self._d_data_src = None  # the host array object that copy was made from
         self._d_scale = None
-        self._plan = None
-        self._trace = None
+        self._plans = {}  # device index -> FilterPlan of the current filter
+        self._last_plan = None
+        self._in_call = False  # inside find_period()/filter_data(): the device copy is current
+
+    # ------------------------------------------------------------------ copying (explorer: _plotting.py:115)
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy(parrm)`` -- the first thing the reference's explorer does
+        (_utils/_plotting.py:115).  Host state is copied like the reference's plain object would be;
+        device state (cached recording, filter plans: raw device pointers) is dropped and rebuilt
+        lazily by the copy; a CUDA-tensor recording is shared, not cloned (it is never written)."""
+        clone = object.__new__(type(self))
+        memo[id(self)] = clone
+        for name, value in self.__dict__.items():
+            if name in self._DEVICE_STATE:
+                continue
+            if _is_device_tensor(value):
+                setattr(clone, name, value)
+            else:
+                setattr(clone, name, copy.deepcopy(value, memo))
+        clone._reset_device_state()
+        return clone
+
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in self._DEVICE_STATE}
+        if _is_device_tensor(state.get("_data")):
+            raise TypeError("a PARRM object holding a CUDA tensor cannot be pickled; pass a NumPy array")
+        if _is_device_tensor(state.get("_filtered_data")):
+            state["_filtered_data"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._reset_device_state()
+
+    @property
+    def _plan(self):
+        """The filter plan most recently used by :meth:`filter_data` (``None`` before that)."""
+        return self._last_plan
 
     def _check_init_inputs(self, data, sampling_freq, artefact_freq, verbose) -> None:
         """parrm.py:112-140 (first failing check wins)."""
@@ -150,9 +204,11 @@ class PARRM:
             if t.dtype not in (torch.float32, torch.float64):
                 t = t.to(torch.float64)
             return t if t.stride(-1) == 1 else t.contiguous()
-        # the cache belongs to one host array OBJECT: the reference's explorer rebinds `_data` to a
-        # time slice (_plotting.py:140-141), after which the old device copy must not be served
-        if own and self._d_data is not None and self._d_data_src is src:
+        # The device copy belongs to one host array OBJECT (the reference's explorer rebinds `_data`
+        # to a time slice, _plotting.py:140-141) and, unless the caller opted into caching, to the
+        # find_period()/filter_data() call that made it: the reference re-reads `self._data` on every
+        # call, so an in-place edit between calls must be seen here too.
+        if own and self._d_data is not None and self._d_data_src is src and (self._in_call or self.cache_on_device):
             return self._d_data
         host = src
         if host.dtype not in (np.float32, np.float64):
@@ -161,13 +217,23 @@ class PARRM:
         if own:
             self._d_data, self._d_data_src = t, src
             self._d_scale = None
+            self._in_call = True  # cleared by _end_call()
         return t
 
+    def _end_call(self) -> None:
+        """End of a public call: without ``cache_on_device`` the device copy of a host recording
+        is not trusted (nor kept) beyond it."""
+        self._in_call = False
+        if not self.cache_on_device:
+            self._d_data = self._d_data_src = self._d_scale = None
+
     def release_device_cache(self) -> None:
-        """Drop the cached device copy of a host recording (e.g. after mutating ``data``)."""
+        """Drop the cached device copy of a host recording (with ``cache_on_device``: call this
+        after modifying ``data`` in place)."""
         self._d_data = None
         self._d_data_src = None
         self._d_scale = None
+        self._in_call = False
 
     # ------------------------------------------------------------------ find_period (a2-a8)
     def find_period(
@@ -188,8 +254,14 @@ class PARRM:
         self._check_sort_find_stim_period_inputs(
             search_samples, assumed_periods, outlier_boundary, random_seed, n_jobs
         )
-        self._standardise_data()
-        self._optimise_period_estimate()
+        self._in_call = False  # a new search always starts from the host array as it is now
+        if not self.cache_on_device:
+            self._d_data = self._d_data_src = None
+        try:
+            self._standardise_data()
+            self._optimise_period_estimate()
+        finally:
+            self._end_call()
         self._say("    ... Artefact period found\n")
 
     def _reset_result_attrs(self) -> None:
@@ -200,7 +272,8 @@ class PARRM:
             "_omit_n_samples", "_filter_direction", "_period_half_width",
         ):
             setattr(self, name, None)
-        self._plan = None
+        self._plans = {}
+        self._last_plan = None
         self._d_scale = None
 
     def _check_sort_find_stim_period_inputs(
@@ -289,8 +362,12 @@ class PARRM:
             y, d_idx = self._stage_matrix(indices)
             stage = (y, d_idx)
 
-            def objective(periods, _y=y, _i=d_idx, _bw=bandwidth):
-                return _hip.fit_errors(_y, _i, periods, _bw, _STAGE_LAMBDA, ws)
+            evals = []
+
+            def objective(periods, _y=y, _i=d_idx, _bw=bandwidth, _log=evals):
+                errors = _hip.fit_errors(_y, _i, periods, _bw, _STAGE_LAMBDA, ws)
+                _log.append((np.array(periods, dtype=np.float64), errors))
+                return errors
 
             grid = self._get_possible_periods(estimate, run)
             errors = _hip.fit_errors(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, ws)
@@ -298,7 +375,7 @@ class PARRM:
             estimate = _refine_candidates(ranked, ranked_errors, objective)
             trace.append(
                 {"indices": indices, "bandwidth": bandwidth, "grid": grid, "errors": errors,
-                 "estimate": float(estimate[0])}
+                 "estimate": float(estimate[0]), "refine_evals": evals}
             )
         if not np.isfinite(estimate[0]):
             raise ValueError(_PERIOD_FAILURE)
@@ -307,10 +384,15 @@ class PARRM:
         y, d_idx = stage
         final_bw = _STAGE_BANDWIDTHS[-1]
 
+        final_evals = []
+
         def final_objective(periods):
-            return _hip.fit_errors(y, d_idx, periods, final_bw, 0.0, ws)
+            errors = _hip.fit_errors(y, d_idx, periods, final_bw, 0.0, ws)
+            final_evals.append((np.array(periods, dtype=np.float64), errors))
+            return errors
 
         self._period = fmin_lockstep(final_objective, [estimate[0]])[0][0][0]
+        trace.append({"final_bandwidth": final_bw, "final_evals": final_evals})
         self._trace = trace
 
     def _get_centre_indices(self, use_n_samples, ignore_portion, random_state) -> np.ndarray:
@@ -482,7 +564,8 @@ class PARRM:
         taps = -taps / np.max((taps.sum(), np.finfo(np.float64).eps))
         taps[hw] = 1
         self._filter = taps
-        self._plan = None  # device tables are rebuilt lazily for the new taps
+        self._plans = {}  # device tables are rebuilt lazily for the new taps
+        self._last_plan = None
 
     # ------------------------------------------------------------------ filter_data (a11)
     def filter_data(self, data=None):
@@ -498,16 +581,29 @@ class PARRM:
                 "be called first."
             )
         data = self._check_sort_filter_data_inputs(data)
-        if self._plan is None:
-            self._plan = _hip.FilterPlan(self._filter)
-        if isinstance(data, np.ndarray) and data.nbytes > _DEVICE_CACHE_BYTES:
-            filtered = self._plan.apply_host(data)
-        else:
-            y = self._plan.apply(self._device_recording(data))
-            filtered = _hip.to_host_numpy(y) if isinstance(data, np.ndarray) else y
+        try:
+            if isinstance(data, np.ndarray) and data.nbytes > _DEVICE_CACHE_BYTES:
+                filtered = self._plan_for(None).apply_host(data)
+            else:
+                x = self._device_recording(data)
+                y = self._plan_for(x.device).apply(x)
+                filtered = _hip.to_host_numpy(y) if isinstance(data, np.ndarray) else y
+        finally:
+            self._end_call()
         self._filtered_data = filtered
         self._say("    ... Data filtered\n")
         return self._filtered_data
+
+    def _plan_for(self, device):
+        """Filter plan on ``device`` (default: the current one).  The plan's tables live in that
+        device's memory, so plans are kept per device index and built with that device current."""
+        torch = _hip.require_gpu()
+        index = torch.cuda.current_device() if device is None or device.index is None else device.index
+        plan = self._plans.get(index)
+        if plan is None:
+            plan = self._plans[index] = _hip.FilterPlan(self._filter, device=index)
+        self._last_plan = plan
+        return plan
 
     def _check_sort_filter_data_inputs(self, data):
         """parrm.py:877-886."""

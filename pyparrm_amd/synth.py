@@ -67,3 +67,35 @@ def synth_recording_device(n_chans: int, n_samples: int, sampling_freq: float, a
         out[:, lo:hi] = (noise + d_gain * art).to(dtype)
         del art, noise, theta
     return out
+
+
+def pulse_shape(u: np.ndarray) -> np.ndarray:
+    """Artefact waveform over one period, ``u`` in [0, 1): a biphasic stimulation pulse (two
+    triangular lobes) on a smooth cubic swell.  Only +, -, *, abs and max are used -- every one
+    exactly rounded -- so the samples are bit-identical on any IEEE-754 host (no libm ``sin``,
+    whose last bit depends on the SIMD path NumPy picks for the CPU at hand)."""
+    lobe_a = np.maximum(0.0, 1.0 - np.abs(u - 0.25) * 20.0)
+    lobe_b = np.maximum(0.0, 1.0 - np.abs(u - 0.35) * 12.0)
+    swell = (u * (1.0 - u)) * (u * (1.0 - u)) * (1.0 - 2.0 * u)
+    return lobe_a - 0.5 * lobe_b + 6.0 * swell
+
+
+def synth_recording_exact(n_chans: int, n_samples: int, period: float, seed: int = 0,
+                          gain_range=(2.0, 10.0), dtype=np.float64) -> np.ndarray:
+    """Recording for cross-host golden fixtures: Gaussian background (NumPy's ziggurat, seeded
+    per channel with ``seed + c``) plus ``gain_c * pulse_shape(((n + off_c) / period) mod 1)``.
+    Everything a fixture needs to store is ``(n_chans, n_samples, period, seed)``; generated in
+    time chunks so that 10 M-sample channels do not need gigabytes of temporaries."""
+    r = np.random.default_rng(seed + 7919)
+    gains = r.uniform(gain_range[0], gain_range[1], n_chans)
+    offsets = r.uniform(0.0, period, n_chans)
+    out = np.empty((n_chans, n_samples), dtype=dtype)
+    chunk = 1 << 21
+    for c in range(n_chans):
+        rng = np.random.default_rng(seed + c)
+        for lo in range(0, n_samples, chunk):
+            hi = min(lo + chunk, n_samples)
+            n = np.arange(lo, hi, dtype=np.float64)
+            u = np.mod((n + offsets[c]) / period, 1.0)
+            out[c, lo:hi] = rng.standard_normal(hi - lo) + gains[c] * pulse_shape(u)
+    return out

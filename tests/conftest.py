@@ -15,6 +15,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # keep the evidence if the process ever dies on a signal (round 1 lost the log of an exit-time
+    # crash): the Python-level stacks of all threads go to gpurun_out/, which gpurun merges back
+    import faulthandler
+
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        config._parrm_fault_log = open(os.path.join(out_dir, f"faulthandler_{os.getpid()}.log"), "w")
+        faulthandler.enable(file=config._parrm_fault_log, all_threads=True)
+    except OSError:
+        faulthandler.enable()
 
 
 @pytest.fixture(scope="session")

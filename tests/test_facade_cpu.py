@@ -273,3 +273,40 @@ def test_explorer_argument_contract():
             p.explore_filter_params(**kwargs)
     with pytest.raises(NotImplementedError):
         p.explore_filter_params()
+
+
+def test_deepcopy_and_pickle_drop_device_state(golden):
+    """The reference object is a plain Python object: its explorer starts with ``deepcopy(parrm)``
+    (_utils/_plotting.py:115).  Host state must be copied, device state dropped (never pickled)."""
+    import copy
+    import pickle
+
+    x = _data((2, 400))
+    p = _with_period(x, 2.0)
+    p.create_filter()
+    sentinel = object()
+    p._d_data, p._d_data_src, p._d_scale = sentinel, x, sentinel  # stand-ins for device state
+    p._plans = {0: sentinel}
+    p._last_plan = sentinel
+    q = copy.deepcopy(p)
+    assert q._d_data is None and q._d_scale is None and q._plans == {} and q._plan is None
+    assert q._data is not p._data and np.array_equal(q._data, p._data)
+    assert q.filter is not p.filter and np.array_equal(q.filter, p.filter)
+    assert q.period == p.period and q.settings["filter"] == p.settings["filter"]
+    # the explorer's next moves (_plotting.py:136-141, :186) work on the copy and leave the original alone
+    q._data = q._data[:, 50:350]
+    q._n_samples = q._data.shape[1]
+    q._check_sort_create_filter_inputs(None, 0, "both", None)
+    q._generate_filter()
+    assert p._n_samples == 400 and p._data.shape == (2, 400)
+    # pickling: same drop list
+    p._plans, p._last_plan, p._d_data, p._d_scale = {}, None, None, None
+    r = pickle.loads(pickle.dumps(p))
+    assert np.array_equal(r.filter, p.filter) and r._plans == {} and r.period == p.period
+
+
+def test_cache_on_device_flag_is_opt_in():
+    p = PARRM(_data(), FS, FA, verbose=False)
+    assert p.cache_on_device is False
+    p.cache_on_device = True
+    assert PARRM.cache_on_device is False

@@ -1,0 +1,298 @@
+"""Round-2 GPU parity tests: the HIP path against periods / outputs written by the UNMODIFIED
+reference (``tests/golden/make_golden_r2.py``) and, at BASELINE configs[2]'s full size, stage by
+stage against the oracle.  Run with ``pytest -m gpu`` on an MI355X.
+
+Tolerances: period |T - T_ref| <= 1e-9 * T_ref AND identical default-filter taps; filtered samples
+max|y - y_ref| <= 1e-9 * max|y_ref| (north_star bar: 1e-6); fit errors rtol 1e-9.
+"""
+
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import parrm_oracle as orc  # noqa: E402
+from pyparrm_amd import PARRM, _hip, get_example_data_paths  # noqa: E402
+from pyparrm_amd.synth import synth_recording, synth_recording_device, synth_recording_exact  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "r2_periods.json")) as fh:
+    R2 = json.load(fh)
+
+PERIOD_RTOL = 1e-9
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _hip.require_gpu()
+    torch.cuda.set_device(0)
+
+
+def _same_default_taps(p_gpu, p_ref, n_samples):
+    hw = orc.default_filter_half_width(n_samples, p_ref, 0, p_ref / 50)
+    a = orc.generate_filter(p_gpu, hw, 0, "both", p_gpu / 50)
+    b = orc.generate_filter(p_ref, hw, 0, "both", p_ref / 50)
+    return np.array_equal(a != 0, b != 0)
+
+
+def _case_recording(case):
+    return synth_recording_exact(case["n_chans"], case["n_samples"], case["period"], case["seed"],
+                                 gain_range=tuple(case["gain"]), dtype=np.dtype(case["dtype"]))
+
+
+def _run_case(case):
+    x = _case_recording(case)
+    p = PARRM(x, case["fs"], case["fa"], verbose=False)
+    kw = {"assumed_periods": tuple(case["assumed"])} if "assumed" in case else {}
+    p.find_period(random_seed=case["random_seed"], **kw)
+    return p
+
+
+# ---------------------------------------------------------------------------- reference periods
+@pytest.mark.parametrize("case", R2["fuzz"] + R2["short"], ids=lambda c: c["tag"])
+def test_period_matches_reference(case):
+    """60 fuzzed recordings + 5 recordings shorter than the stage lengths (parrm.py:288-301: the
+    stage list collapses to 1 or 2 runs), each against the reference's own period."""
+    ref = case["ref_period"]
+    p = _run_case(case)
+    assert abs(p.period - ref) <= PERIOD_RTOL * ref, (case["tag"], p.period, ref)
+    assert _same_default_taps(p.period, ref, case["n_samples"])
+
+
+@pytest.mark.parametrize("case", R2["grid26"], ids=lambda c: c["tag"])
+def test_period_1e4_grid_matches_reference(case):
+    """BASELINE configs[2]'s search -- 26 assumed periods -> 10 044 stage-1 candidates -- on 2 ch x 10 M
+    and 3 ch x 4 M recordings, against the reference's period."""
+    ref = case["ref_period"]
+    p = _run_case(case)
+    assert len(p._trace[0]["grid"]) == 10044
+    assert abs(p.period - ref) <= PERIOD_RTOL * ref, (p.period, ref)
+    assert _same_default_taps(p.period, ref, case["n_samples"])
+
+
+@pytest.mark.parametrize("case", R2["float32"], ids=lambda c: c["tag"])
+def test_period_float32_recording_matches_reference(case):
+    """float32 recordings: the reference standardises in float32 (parrm.py:272-280 keeps the dtype of
+    ``np.diff``); the device path differences in float32 too and must land on the same period."""
+    ref = case["ref_period"]
+    p = _run_case(case)
+    assert abs(p.period - ref) <= PERIOD_RTOL * ref, (p.period, ref)
+    assert _same_default_taps(p.period, ref, case["n_samples"])
+
+
+def test_per_site_periods_match_reference(golden):
+    """examples/plot_example_dbs_data.py:52-98: ECoG + LFP together, ECoG alone, LFP alone."""
+    g = golden("r2_per_site.npz")
+    x = np.load(get_example_data_paths("ecog_lfp_data"))
+    for name, rows in (("both", [0, 1]), ("ecog", [0]), ("lfp", [1])):
+        p = PARRM(x[rows], 1000, 130, verbose=False)
+        p.find_period(random_seed=44)
+        ref = float(g[name])
+        assert abs(p.period - ref) <= PERIOD_RTOL * ref, (name, p.period, ref)
+        assert _same_default_taps(p.period, ref, x.shape[1])
+
+
+def test_config1_flow_matches_reference(golden):
+    """BASELINE configs[0]: 1 ch x 60 s @ 22 kHz through find_period -> create_filter -> filter_data
+    (examples/plot_use_parrm.py:77-141 sequence), against the reference run on the same recording."""
+    g = golden("r2_cfg1_flow.npz")
+    n = int(g["n_samples"])
+    x = synth_recording_exact(1, n, float(g["true_period"]), int(g["seed"]))
+    p = PARRM(x, 22000.0, 130.0, verbose=False)
+    p.find_period(random_seed=int(g["random_seed"]))
+    ref = float(g["period"])
+    assert abs(p.period - ref) <= PERIOD_RTOL * ref, (p.period, ref)
+    p.create_filter()
+    assert p.settings["filter"]["filter_half_width"] == int(g["default_half_width"])
+    for tag, kwargs in (("default", {}),
+                        ("explicit", dict(filter_half_width=4000, omit_n_samples=20,
+                                          filter_direction="both", period_half_width=1.0))):
+        p.create_filter(**kwargs)
+        assert np.array_equal(np.flatnonzero(p.filter), g[f"{tag}_filter_taps"]), tag
+        y = p.filter_data()
+        assert y.shape == (1, n) and y.dtype == np.float64
+        scale = float(np.abs(g[f"{tag}_y_strided"]).max())
+        for got, want in ((y[0, ::997], g[f"{tag}_y_strided"]), (y[0, :6000], g[f"{tag}_y_head"]),
+                          (y[0, -6000:], g[f"{tag}_y_tail"])):
+            assert np.abs(got - want).max() <= 1e-9 * scale, tag
+
+
+# ---------------------------------------------------------------------------- singular systems
+def test_fit_errors_singular_is_inf_like_linalgerror():
+    """parrm.py:625-628: ``LinAlgError`` -> (inf, inf) -> ``_optimise_local`` returns inf (:592-593).
+    An infinite period makes every angle 0: sin columns exactly 0, cos columns exactly 1 -> W'W has
+    exactly zero rows and exact duplicates -> LAPACK reports a zero pivot; a huge finite period keeps
+    the cos columns exactly 1 (duplicates).  The device LU must map both to +inf, and leave the
+    ordinary candidate between them untouched."""
+    x = synth_recording(3, 30000, 22000, 130, seed=2)
+    idx = np.arange(12000, 17001)
+    d_x = torch.from_numpy(x).cuda()
+    d_idx = torch.from_numpy(idx).cuda()
+    y = _hip.gather_standardise(d_x, d_idx, _hip.absdiff_mean(d_x), 3.0)
+    std = orc.standardise_data(x, 3.0)
+    periods = np.array([np.inf, 169.2358, 1e300, 169.3])
+    for bw in (5, 10, 20):
+        ref = orc.grid_errors(periods, std, idx, bw, 1.0)
+        assert np.isposinf(ref[0]) and np.isposinf(ref[2]) and np.isfinite(ref[1]) and np.isfinite(ref[3])
+        got = _hip.fit_errors(y, d_idx, periods, bw, 1.0)
+        assert np.isposinf(got[0]) and np.isposinf(got[2]), got
+        np.testing.assert_allclose(got[[1, 3]], ref[[1, 3]], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------- explorer (f1)
+def test_explorer_protocol_starts_with_deepcopy():
+    """_utils/_plotting.py:115 ``deepcopy(parrm)`` AFTER the object has filtered (plans and a device
+    copy exist), then the `_data` rebind (:136-141), `_check_sort_create_filter_inputs(None, 0,
+    "both", None)` (:186) and the per-event `_generate_filter()` + `filter_data()` (:568-584)."""
+    x = synth_recording(2, 60000, 22000, 130, seed=9)
+    p = PARRM(x, 22000, 130, verbose=False)
+    p.cache_on_device = True
+    p.find_period(random_seed=1)
+    p.create_filter()
+    first = p.filter_data()
+    assert p._plan is not None and p._d_data is not None
+    q = copy.deepcopy(p)
+    assert q._plan is None and q._d_data is None and q._data is not p._data
+    assert np.array_equal(q._data, p._data) and q.period == p.period
+    assert np.array_equal(q.filtered_data, first)
+    q._verbose = False
+    time_range = np.arange(5000, 45000)
+    q._data = q._data[:, time_range]
+    q._n_samples = q._data.shape[1]
+    q._check_sort_create_filter_inputs(None, 0, "both", None)
+    for hw, phw, omit, direction in ((q._filter_half_width, q._period / 50, 0, "both"),
+                                      (1500, 2.0, 10, "past"), (900, 4.5, 0, "future")):
+        q._filter_half_width, q._period_half_width = hw, phw
+        q._omit_n_samples, q._filter_direction = omit, direction
+        q._generate_filter()
+        out = q.filter_data()
+        ref = orc.filter_data_direct(x[:, time_range], orc.generate_filter(q._period, hw, omit, direction, phw))
+        assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
+    # the original is untouched by what the copy did
+    assert p._n_samples == 60000 and np.array_equal(p.filter_data(), first)
+
+
+def test_inplace_edit_between_calls_is_seen():
+    """The reference reads ``self._data`` on every call (parrm.py:274, :861): zeroing a bad segment in
+    place between two ``filter_data()`` calls changes the second result.  (stale cache.)"""
+    x = synth_recording(2, 40000, 22000, 130, seed=3)
+    p = PARRM(x, 22000, 130, verbose=False)
+    p._period = np.float64(169.2359)
+    p.create_filter()
+    y0 = p.filter_data().copy()
+    x[:, 10000:12000] = 0.0
+    y1 = p.filter_data()
+    ref = orc.filter_data_direct(x, p.filter)
+    assert np.abs(y1 - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(y1 - y0).max() > 1.0
+    # opted-in caching keeps the device copy; release_device_cache() re-reads
+    p.cache_on_device = True
+    p.filter_data()
+    x[:, 20000:21000] = 0.0
+    stale = p.filter_data()
+    assert np.abs(stale - ref).max() <= 1e-10 * np.abs(ref).max()
+    p.release_device_cache()
+    fresh = p.filter_data()
+    ref2 = orc.filter_data_direct(x, p.filter)
+    assert np.abs(fresh - ref2).max() <= 1e-10 * np.abs(ref2).max()
+
+
+def test_plan_is_bound_to_its_device():
+    """a plan's tables live on one device; serving a recording on another must
+    fail cleanly, never launch.  With one GPU the C-side check is exercised through a plan whose
+    recorded device is wrong."""
+    filt = orc.generate_filter(169.2359, 2372)
+    plan = _hip.FilterPlan(filt, device=0)
+    x = torch.zeros((1, 6000), dtype=torch.float64, device="cuda:0")
+    plan.apply(x)
+    plan.device = 1  # pretend: the Python-side guard compares with the tensor's device
+    with pytest.raises(ValueError, match="lives on cuda:1"):
+        plan.apply(x)
+    plan.device = 0
+    if torch.cuda.device_count() > 1:
+        other = torch.zeros((1, 6000), dtype=torch.float64, device="cuda:1")
+        with pytest.raises(ValueError, match="lives on cuda:0"):
+            plan.apply(other)
+        with torch.cuda.device(1):  # C-side guard: plan of device 0 while device 1 is current
+            rc = _hip.lib().parrm_filter_apply(plan._h, other.data_ptr(), _hip.F64, other.data_ptr(), _hip.F64,
+                                               1, 6000, 6000, 6000, None)
+            assert rc == 1
+        p = PARRM(other, 22000, 130, verbose=False)
+        p._period = np.float64(169.2359)
+        p.create_filter()
+        assert p.filter_data().device == other.device
+
+
+# ---------------------------------------------------------------------------- config 3, find_period leg
+def _assumed_1e4():
+    base = 22000.0 / 130.0
+    return tuple(base * (1 + 0.02 * k) for k in range(-13, 13))
+
+
+def test_config3_find_period_stage_by_stage_vs_oracle():
+    """BASELINE configs[2] at full size: 256 ch x 10 M f64, find_period over the 10 044-candidate grid.
+    The oracle cannot run the whole search on 256 channels (hours), but every piece of it can be
+    checked on the stage columns the search actually used (``PARRM._trace``):
+      * scale (mean |diff|) and the gathered, clipped stage matrix against NumPy on the host;
+      * per stage, device grid errors against the oracle objective on a sample of candidates that
+        always includes the five Nelder-Mead starts, and the ranking of those starts;
+      * a sample of the Nelder-Mead evaluations of every stage and of the final polish;
+      * the period against the generator's true period and the reference-formulated taps."""
+    n_chans, n_samples = 256, 10_000_000
+    x = synth_recording_device(n_chans, n_samples, 22000.0, 130.0, seed=0)
+    p = PARRM(x, 22000.0, 130.0, verbose=False)
+    p.find_period(assumed_periods=_assumed_1e4(), random_seed=44)
+    trace = p._trace
+    true_period = 22000.0 / 130.0 * (1 + 3e-5)
+    assert abs(p.period - true_period) <= 2e-6 * true_period
+    assert [len(t["grid"]) for t in trace[:3]] == [10044, 387, 381]
+
+    # host copies: scale per channel from the full rows (streamed), stage columns gathered on the device
+    scale = np.empty(n_chans)
+    for c in range(n_chans):
+        row = x[c].cpu().numpy()
+        scale[c] = np.abs(np.diff(row)).mean()
+    d_scale = _hip.absdiff_mean(x)
+    np.testing.assert_allclose(d_scale.cpu().numpy(), scale, rtol=1e-12)
+
+    rng = np.random.default_rng(5)
+    budget = {0: 48, 1: 16, 2: 5}  # oracle evaluations per stage beyond the starts (256 channels each)
+    for run, t in enumerate(trace[:3]):
+        idx = t["indices"]
+        d_idx = torch.from_numpy(idx).cuda()
+        cols = (x[:, d_idx + 1] - x[:, d_idx]).cpu().numpy()  # np.diff(x)[:, idx]
+        std_cols = np.clip(cols / scale[:, None], -3.0, 3.0)  # parrm.py:275-278
+        y = _hip.gather_standardise(x, d_idx, d_scale, 3.0).cpu().numpy()
+        np.testing.assert_allclose(y.T, std_cols, rtol=1e-12, atol=1e-15)
+
+        bw = t["bandwidth"]
+        errors, grid = t["errors"], t["grid"]
+        order = np.argsort(errors)
+        starts = order[:5]
+        sample = np.unique(np.concatenate([starts, rng.choice(len(grid), budget[run], replace=False)]))
+        ref = np.array([orc.fit_error_gathered(grid[i], std_cols, n_chans, idx, bw, 1.0) for i in sample])
+        np.testing.assert_allclose(errors[sample], ref, rtol=1e-9)
+        # the five starts come out in the oracle's order too
+        ref_starts = np.array([ref[np.searchsorted(sample, i)] for i in starts])
+        assert np.all(np.diff(ref_starts) >= 0)
+        # Nelder-Mead evaluations of this stage
+        pts = np.concatenate([e[0] for e in t["refine_evals"]])
+        val = np.concatenate([e[1] for e in t["refine_evals"]])
+        pick = rng.choice(len(pts), 4 if run == 2 else 8, replace=False)
+        ref_nm = np.array([orc.fit_error_gathered(pts[i], std_cols, n_chans, idx, bw, 1.0) for i in pick])
+        np.testing.assert_allclose(val[pick], ref_nm, rtol=1e-9)
+    # final polish: lambda 0, bandwidth 20 unclipped, stage-3 columns (parrm.py:524-550)
+    fin = trace[3]
+    pts = np.concatenate([e[0] for e in fin["final_evals"]])
+    val = np.concatenate([e[1] for e in fin["final_evals"]])
+    pick = rng.choice(len(pts), 3, replace=False)
+    ref_fin = np.array([orc.fit_error_gathered(pts[i], std_cols, n_chans, idx, 20, 0.0) for i in pick])
+    np.testing.assert_allclose(val[pick], ref_fin, rtol=1e-9)
+    # the accepted period is the best vertex the polish saw
+    assert val.min() <= val[np.argmin(np.abs(pts - p.period))] + 1e-15

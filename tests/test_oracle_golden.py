@@ -5,6 +5,8 @@ Pins: (1) ``matlab_filtered.npy`` -- the reference's only numerical known-answer
 ``tests/golden/make_golden.py`` from the unmodified reference.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -152,3 +154,33 @@ def test_filter_data_f32_promotes(golden):
     y = orc.filter_data_fft(g["synth_x"].astype(np.float32), filt)
     assert y.dtype == np.float64
     np.testing.assert_array_equal(y, g["synth_f32_y"])
+
+
+# ---------------------------------------------------------------------------- round-2 fixtures
+def _r2():
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r2_periods.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("tag", ["short0", "short1", "short2", "short4", "fuzz00", "fuzz07", "fuzz09", "fuzz37"])
+def test_oracle_period_matches_reference_r2(tag):
+    """The oracle's whole search against periods written by the unmodified reference
+    (tests/golden/make_golden_r2.py), including recordings shorter than the stage lengths
+    (parrm.py:288-301) -- bit for bit."""
+    from pyparrm_amd.synth import synth_recording_exact
+
+    fixtures = _r2()
+    case = next(c for c in fixtures["fuzz"] + fixtures["short"] if c["tag"] == tag)
+    x = synth_recording_exact(case["n_chans"], case["n_samples"], case["period"], case["seed"],
+                              gain_range=tuple(case["gain"]))
+    got = orc.find_period(x, case["fs"], case["fa"], random_seed=case["random_seed"])
+    assert float(got) == case["ref_period"]
+
+
+def test_r2_fixture_inventory():
+    fixtures = _r2()
+    assert len(fixtures["fuzz"]) == 60 and len(fixtures["short"]) == 5
+    assert len(fixtures["grid26"]) == 2 and len(fixtures["float32"]) == 3
+    assert all(c["ref_period"] is not None for group in fixtures.values() for c in group)
