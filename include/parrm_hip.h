@@ -167,6 +167,18 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
                      double lambda, double *d_err, void *d_workspace, size_t workspace_bytes,
                      void *stream);
 
+/* Slice form for a candidate grid that is split over several calls (several GPUs: candidates are
+ * independent, parrm.py:445-454 maps over them): evaluates `n_periods` candidates of a grid of
+ * `grid_periods` candidates with the work split the whole grid would get, so that every candidate's
+ * error is bit-identical to what ONE call on the whole grid returns, wherever the grid is cut.
+ * parrm_fit_errors is the grid_periods == n_periods case. */
+size_t parrm_fit_slice_workspace_bytes(int64_t n_idx, int64_t n_chans, int64_t n_periods,
+                                       int64_t grid_periods, int bw);
+int parrm_fit_errors_slice(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
+                           int64_t n_chans, const double *d_periods, int64_t n_periods,
+                           int64_t grid_periods, int bw, double lambda, double *d_err,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Same computation with the candidate periods and the errors in HOST memory: copies the periods
  * in, runs parrm_fit_errors on `stream`, copies the errors out and synchronises the stream -- one
  * call per optimiser step (the Nelder-Mead phase of parrm.py:510-517,545-550 is a chain of small,

@@ -39,6 +39,8 @@ SYMBOLS = (
     "parrm_gather_standardise",
     "parrm_fit_workspace_bytes",
     "parrm_fit_errors",
+    "parrm_fit_slice_workspace_bytes",
+    "parrm_fit_errors_slice",
     "parrm_fit_errors_host",
 )
 
@@ -138,6 +140,10 @@ def lib() -> C.CDLL:
         L.parrm_fit_workspace_bytes.argtypes = [i64, i64, i64, i32]
         L.parrm_fit_errors.restype = i32
         L.parrm_fit_errors.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
+        L.parrm_fit_slice_workspace_bytes.restype = C.c_size_t
+        L.parrm_fit_slice_workspace_bytes.argtypes = [i64, i64, i64, i64, i32]
+        L.parrm_fit_errors_slice.restype = i32
+        L.parrm_fit_errors_slice.argtypes = [vp, i64, vp, i64, i64, vp, i64, i64, i32, dbl, vp, vp, C.c_size_t, vp]
         L.parrm_fit_errors_host.restype = i32
         L.parrm_fit_errors_host.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
         if L.parrm_hip_abi_version() != 2:
@@ -449,10 +455,10 @@ class FitWorkspace:
             self._buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
         return self._buf
 
-    def nbytes(self, n_idx: int, n_chans: int, n_per: int, bandwidth: int) -> int:
-        key = (n_idx, n_chans, n_per, bandwidth)
+    def nbytes(self, n_idx: int, n_chans: int, n_per: int, bandwidth: int, grid: int = 0) -> int:
+        key = (n_idx, n_chans, n_per, bandwidth, grid)
         if key not in self._sizes:
-            self._sizes[key] = lib().parrm_fit_workspace_bytes(n_idx, n_chans, n_per, bandwidth)
+            self._sizes[key] = lib().parrm_fit_slice_workspace_bytes(n_idx, n_chans, n_per, max(grid, n_per), bandwidth)
         return self._sizes[key]
 
     def staging(self, n_per: int, device):
@@ -466,11 +472,16 @@ class FitWorkspace:
         return self._h_per, self._h_err, self._d_per, self._d_err
 
 
-def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, workspace: FitWorkspace | None = None):
+def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, workspace: FitWorkspace | None = None,
+               grid_periods: int = 0):
     """Channel-averaged regularised fit error of every candidate period (parrm.py:552-632).
 
     ``y`` is the [n_idx, C] matrix from :func:`gather_standardise`, ``idx`` the int64 device vector
     of sample indices.  Returns a float64 NumPy vector (one blocking read-back per call).
+
+    ``grid_periods``: ``periods`` is a slice of a grid of that many candidates evaluated over several
+    calls / GPUs; each candidate's error is then bit-identical to a single call on the whole grid
+    (``parrm_fit_errors_slice``).
     """
     torch = require_gpu()
     L = lib()
@@ -483,10 +494,13 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
     if ws.nbytes(n_idx, n_chans, 1, bandwidth) == 0:
         raise HipLibraryError("parrm_fit_workspace_bytes rejected the problem shape")
     # batch so that the scratch stays bounded
+    grid = int(grid_periods) if grid_periods and grid_periods > n_per else 0
     batch = min(n_per, 65535)
-    while batch > 1 and ws.nbytes(n_idx, n_chans, batch, bandwidth) > FitWorkspace.MAX_BYTES:
+    while batch > 1 and ws.nbytes(n_idx, n_chans, batch, bandwidth, grid) > FitWorkspace.MAX_BYTES:
         batch = (batch + 1) // 2
-    if batch == n_per:
+    if batch != n_per and not grid:
+        grid = n_per  # a grid cut only to bound the scratch is still planned as one grid
+    if batch == n_per and not grid:
         # one fused call: periods in, kernels, errors out, stream sync (the optimiser's small batches)
         nbytes = ws.nbytes(n_idx, n_chans, n_per, bandwidth) + 16 * n_per
         buf = ws.get(nbytes, y.device)
@@ -508,15 +522,15 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
         d_per[:n_per].copy_(h_per[:n_per], non_blocking=True)
         for lo in range(0, n_per, batch):
             cnt = min(batch, n_per - lo)
-            nbytes = ws.nbytes(n_idx, n_chans, cnt, bandwidth)
+            nbytes = ws.nbytes(n_idx, n_chans, cnt, bandwidth, grid)
             buf = ws.get(nbytes, y.device)
             check(
-                L.parrm_fit_errors(
+                L.parrm_fit_errors_slice(
                     y.data_ptr(), y.stride(0), idx.data_ptr(), n_idx, n_chans,
-                    d_per.data_ptr() + 8 * lo, cnt, int(bandwidth), float(lambda_),
+                    d_per.data_ptr() + 8 * lo, cnt, max(grid, cnt), int(bandwidth), float(lambda_),
                     d_err.data_ptr() + 8 * lo, buf.data_ptr(), nbytes, stream,
                 ),
-                "parrm_fit_errors",
+                "parrm_fit_errors_slice",
             )
         h_err[:n_per].copy_(d_err[:n_per], non_blocking=True)
         torch.cuda.current_stream().synchronize()

@@ -755,13 +755,18 @@ struct FitGeom {
     size_t red_bytes;    // reduced blocks (0 when nsplit == 1: part is used in place)
 };
 
-FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) {
+// `plan_periods` (>= n_periods): the candidate count the sample split is chosen for.  A slice of a
+// larger grid is planned as the whole grid would be, so that every candidate goes through exactly the
+// arithmetic (slices per candidate, order of the partial sums) it would see in one call on the whole
+// grid -- what makes a candidate-sliced, multi-GPU evaluation bit-identical to the one-GPU one.
+FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw, int64_t plan_periods = 0) {
     FitGeom g{};
     g.KP = kp_for(bw);
     g.nz = static_cast<int>((n_chans + kYCols - 1) / kYCols);
     g.n_pad = static_cast<int>((n_idx + kTJ - 1) / kTJ * kTJ);
     const int64_t tiles = g.n_pad / kTJ;
     const int64_t groups = (n_periods + (48 / g.KP) - 1) / (48 / g.KP);  // workgroups per sample slice
+    const int64_t plan_groups = plan_periods > n_periods ? (plan_periods + (48 / g.KP) - 1) / (48 / g.KP) : groups;
     // Sample slices per candidate group.  512 workgroups are resident at once (2 per CU), so the run
     // time is ~ceil(workgroups / 512) rounds of (work per workgroup ~ 1/nsplit): pick the nsplit
     // that minimises rounds/nsplit (e.g. 381 candidates: nsplit 2 -> 762 workgroups = 2 rounds,
@@ -772,7 +777,7 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) 
     double best = 1e300;
     g.nsplit = 1;
     for (int64_t ns = 1; ns <= max_split; ++ns) {
-        const int64_t rounds = (groups * g.nz * ns + resident - 1) / resident;
+        const int64_t rounds = (plan_groups * g.nz * ns + resident - 1) / resident;
         const double cost = static_cast<double>(rounds) / static_cast<double>(ns) * (1.0 + 0.004 * ns);
         if (cost < best - 1e-12) {
             best = cost;
@@ -915,21 +920,34 @@ int parrm_gather_standardise(const void *d_x, int x_dtype, int64_t n_chans, int6
 }
 
 size_t parrm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw) {
-    if (n_idx <= 0 || n_chans <= 0 || n_periods <= 0 || bw < 0 || bw > kMaxBw) return 0;
-    const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw);
+    return parrm_fit_slice_workspace_bytes(n_idx, n_chans, n_periods, n_periods, bw);
+}
+
+size_t parrm_fit_slice_workspace_bytes(int64_t n_idx, int64_t n_chans, int64_t n_periods, int64_t grid_periods,
+                                       int bw) {
+    if (n_idx <= 0 || n_chans <= 0 || n_periods <= 0 || grid_periods < n_periods || bw < 0 || bw > kMaxBw) return 0;
+    const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw, grid_periods);
     return g.w_bytes + g.part_bytes + g.red_bytes;
 }
 
 int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
                      const double *d_periods, int64_t n_periods, int bw, double lambda, double *d_err,
                      void *d_workspace, size_t workspace_bytes, void *stream) {
+    return parrm_fit_errors_slice(d_y, ldy, d_idx, n_idx, n_chans, d_periods, n_periods, n_periods, bw, lambda, d_err,
+                                  d_workspace, workspace_bytes, stream);
+}
+
+int parrm_fit_errors_slice(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
+                           const double *d_periods, int64_t n_periods, int64_t grid_periods, int bw, double lambda,
+                           double *d_err, void *d_workspace, size_t workspace_bytes, void *stream) {
     PARRM_REQUIRE(d_y && d_idx && d_periods && d_err && d_workspace, "fit_errors: NULL argument");
+    PARRM_REQUIRE(grid_periods >= n_periods, "fit_errors: a slice cannot be longer than its grid");
     PARRM_REQUIRE(bw >= 0 && bw <= kMaxBw, "fit_errors: bandwidth %d outside [0, %d]", bw, kMaxBw);
     PARRM_REQUIRE(n_idx > 0 && n_idx < (int64_t{1} << 30) && n_chans > 0 && n_chans < (int64_t{1} << 24) &&
                       ldy >= n_chans,
                   "fit_errors: bad shape");
     PARRM_REQUIRE(n_periods > 0 && n_periods <= 65535, "fit_errors: 1..65535 periods per call");
-    const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw);
+    const FitGeom g = fit_geometry(n_idx, n_chans, n_periods, bw, grid_periods);
     if (workspace_bytes < g.w_bytes + g.part_bytes + g.red_bytes) {
         parrm::set_error("fit_errors: workspace too small (%zu < %zu)", workspace_bytes,
                          g.w_bytes + g.part_bytes + g.red_bytes);

@@ -344,6 +344,11 @@ class PARRM:
         y = _hip.gather_standardise(x, d_idx, self._d_scale, self._outlier_boundary)
         return y, d_idx
 
+    def _grid_errors(self, y, d_idx, grid: np.ndarray, bandwidth: int, workspace) -> np.ndarray:
+        """Errors of a whole candidate grid (the ordered map of parrm.py:445-454).  One device call
+        here; ``sharding.ShardedPARRM`` cuts the grid into per-rank slices instead."""
+        return _hip.fit_errors(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, workspace)
+
     def _optimise_period_estimate(self) -> None:
         """Three coarse-to-fine stages + an un-regularised polish (parrm.py:282-325)."""
         rng = np.random.default_rng(self._random_seed)
@@ -370,7 +375,7 @@ class PARRM:
                 return errors
 
             grid = self._get_possible_periods(estimate, run)
-            errors = _hip.fit_errors(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, ws)
+            errors = self._grid_errors(y, d_idx, grid, bandwidth, ws)
             ranked, ranked_errors = _rank_candidates(grid, errors)
             estimate = _refine_candidates(ranked, ranked_errors, objective)
             trace.append(
