@@ -4,24 +4,31 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU one
-256 ch x 10 Msample float64 synthetic recording (22 kHz sampling, 130 Hz artefact)
-resident in HBM before the timed region.  One *step* = one full pass of the hot path over it:
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): ONE 256 ch x
+10 Msample float64 synthetic recording (22 kHz sampling, 130 Hz artefact) resident in
+HBM before the timed region.  One *step* = one full pass of the hot path over it:
 
     find_period over a ~1e4-point period grid (26 assumed periods, 2 % apart -> 10 044 candidates
     in stage 1, then the reference's stages 2-3 and the final polish)  ->  create_filter()
     (defaults: hw 2372, 196 taps)  ->  filter_data()
 
-Multi-GPU: recordings are independent units (per-site period estimation, one PARRM per rank),
-one process per GPU, no data-path collective: weak scaling.  Only the timing uses
-torch.distributed (barrier + MAX over ranks).
+Multi-GPU (configs[3]): one process per GPU.  Default ``--mode strong``: the SAME recording,
+channel-sharded (rank r builds and holds rows ``channel_shard(256, r, N)``); ``filter_data`` and the
+statistics pass run on the rank's rows with no exchange, the candidate grids are cut into per-rank
+slices over a replicated stage matrix (``pyparrm_amd.sharding.ShardedPARRM``: two small all-gathers
+per stage on the launcher's process group -- the path's one real exchange step), the Nelder-Mead
+chains run redundantly.  ``value`` = 256 x 10 M samples per step / time: strong scaling.
+``--mode weak``: one independent 256 x 10 M recording and one ``PARRM`` per rank (per-site period
+estimation, examples/plot_example_dbs_data.py:52-98), no exchange at all.
+Started without a launcher (no WORLD_SIZE) and ``--gpus N > 1``, this script starts the N rank
+processes itself -- before it touches the GPU -- and exits with their status.
 
 The JSON line also carries
   roofline      the filter_data kernel against HBM: algorithmic 16 B/sample x
                 C x N per launch / the launch's duration from HIP events on its stream;
-  cpu_baseline  the oracle (the reference's own formulation: NumPy/LAPACK regression,
-                scipy fftconvolve, scipy fmin) timed on this host on ONE channel of the same
-                recording (all 10 M samples, same 1e4 grid) -- rank 0, N=1 only.
+  cpu_baseline  ``oracle/cpu_baseline.py`` (the reference's own formulation on the host cores: configs[0]
+                and configs[1] in full, configs[2] on 8 of its 256 channels), run as a child process
+                before the GPU is touched -- rank 0, N=1 only.
 """
 
 from __future__ import annotations
@@ -29,6 +36,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,61 +64,58 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chans", type=int, default=256)
     ap.add_argument("--samples", type=int, default=10_000_000)
+    ap.add_argument("--mode", choices=["strong", "weak"], default="strong",
+                    help="N > 1: one recording channel-sharded (strong) or one recording per rank (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-only", action="store_true", help="time filter_data alone (config 2 style)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
-def cpu_baseline(channel: np.ndarray):
-    """Oracle on one channel of the same recording; returns the cpu_baseline object."""
-    from oracle import parrm_oracle as orc
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as child processes.  Nothing in
+    this process has touched the GPU yet (no torch import, no HIP call), and nothing will."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c != 0), 0)
 
-    try:
-        from threadpoolctl import threadpool_info
 
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = 1
-    x = np.ascontiguousarray(channel[None, :])
-    t0 = time.perf_counter()
-    period = orc.find_period(x, FS, F_ART, assumed_periods=assumed_periods_1e4(), random_seed=44)
-    t_find = time.perf_counter() - t0
-    hw = orc.default_filter_half_width(x.shape[1], period, 0, period / 50)
-    filt = orc.generate_filter(period, hw, 0, "both", None)
-    t0 = time.perf_counter()
-    orc.filter_data_fft(x, filt)
-    t_filt = time.perf_counter() - t0
-    total = t_find + t_filt
-    return {
-        "value": x.size / total / 1e6,
-        "unit": "Msamples/s",
-        "cores": int(threads),
-        "kind": "port",
-        "sample": (
-            f"1 of the recording's channels x {x.shape[1]} samples, same 1e4-candidate find_period "
-            f"(oracle: NumPy/LAPACK fits + scipy fmin, {t_find:.1f} s) + filter_data as two scipy "
-            f"fftconvolve calls ({t_filt:.1f} s); host has {os.cpu_count()} logical CPUs, BLAS "
-            f"threads {threads}; find_period cost is per channel, so Msamples/s scales with N"
-        ),
-        "period": float(period),
-    }, float(period)
+def run_cpu_baseline():
+    """The oracle on the host cores, as a child process that never sees the GPU."""
+    res = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline"], cwd=ROOT, capture_output=True, text=True)
+    if res.returncode != 0:
+        return {"error": res.stderr[-400:]}
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    return {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "period", "configs", "wall_s")}
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = run_cpu_baseline()  # before this process initialises the GPU
 
     import torch
 
     from pyparrm_amd import PARRM, _hip
-    from pyparrm_amd.sharding import timed_steps
+    from pyparrm_amd.sharding import ShardedPARRM, TorchExchange, channel_shard, timed_steps
     from pyparrm_amd.synth import synth_recording_device
 
     _hip.require_gpu()
@@ -118,7 +124,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
-        import torch.distributed as dist  # nccl == RCCL; used for the timing barrier / MAX only
+        import torch.distributed as dist  # nccl == RCCL
 
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -126,7 +132,13 @@ def main():
             dist.init_process_group(args.backend)
 
     n_chans, n_samples = args.chans, args.samples
-    x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
+    strong = world > 1 and args.mode == "strong"
+    if strong:
+        lo, hi = channel_shard(n_chans, rank, world)
+        x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=0, chan_range=(lo, hi))
+        exchange = TorchExchange(dist)
+    else:
+        x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
     torch.cuda.synchronize()
     assumed = assumed_periods_1e4()
 
@@ -134,7 +146,7 @@ def main():
     state = {}
 
     def step(record: bool):
-        p = PARRM(x, FS, F_ART, verbose=False)
+        p = ShardedPARRM(x, FS, F_ART, exchange, verbose=False) if strong else PARRM(x, FS, F_ART, verbose=False)
         t0 = time.perf_counter()
         if args.filter_only and "period" in state:
             p._period = state["period"]
@@ -151,34 +163,40 @@ def main():
         (ev0, ev1), = _hip.FILTER_LAUNCH_EVENTS
         _hip.FILTER_LAUNCH_EVENTS = None
         state.update(period=p.period, filt=p.filter, info=p._plan.info)
-        del y, p  # the 20 GB output goes back to torch's caching allocator for the next step
+        del y, p  # the output goes back to torch's caching allocator for the next step
         if record:
             timings["find"].append(t1 - t0)
             timings["filter_total"].append(t2 - t1)
             timings["filter_kernel"].append(ev0.elapsed_time(ev1) * 1e-3)
 
     # W untimed warm-up steps, then exactly K steps between two sync+barrier fences; MAX over ranks
-    elapsed = timed_steps(lambda: step(True), args.steps, 0, dist=dist, sync=torch.cuda.synchronize) \
-        if args.warmup == 0 else None
-    if elapsed is None:
-        for _ in range(args.warmup):
-            step(False)
-        elapsed = timed_steps(lambda: step(True), args.steps, 0, dist=dist, sync=torch.cuda.synchronize)
+    for _ in range(args.warmup):
+        step(False)
+    elapsed = timed_steps(lambda: step(True), args.steps, 0, dist=dist, sync=torch.cuda.synchronize)
 
     if rank == 0:
-        total_samples = world * n_chans * n_samples * args.steps
+        rows = x.shape[0]
+        total_samples = (1 if strong else world) * n_chans * n_samples * args.steps
         kern_s = float(np.mean(timings["filter_kernel"]))
-        achieved = FILTER_BYTES_PER_SAMPLE * n_chans * n_samples / kern_s / 1e9
+        achieved = FILTER_BYTES_PER_SAMPLE * rows * n_samples / kern_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                if rec.get("chans") == n_chans and rec.get("samples") == n_samples:
+                if rec.get("chans") == rows and rec.get("samples") == n_samples:
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
         info = state["info"]
+        if world == 1:
+            parallelism = "1 GPU"
+        elif strong:
+            parallelism = (f"one recording, channel blocks of {rows} rows on {world} GPUs; filter_data and the statistics "
+                           "pass without exchange, candidate grids in per-rank slices over a replicated stage matrix "
+                           f"(2 all-gathers per stage on the {args.backend} process group), Nelder-Mead replicated")
+        else:
+            parallelism = f"{world} independent recordings, one per GPU, no exchange"
         out = {
             "metric": "Msamples/s through find_period+filter_data",
             "value": total_samples / elapsed / 1e6,
@@ -188,18 +206,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.mode,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": (
-                    f"{n_chans} ch x {n_samples} samples float64 per GPU, 22 kHz / 130 Hz synthetic DBS; "
+                    f"{n_chans} ch x {n_samples} samples float64"
+                    + (" per GPU" if world > 1 and not strong else "")
+                    + ", 22 kHz / 130 Hz synthetic DBS; "
                     + ("filter_data only (period reused)" if args.filter_only else
                        f"find_period over {len(PARRM._get_possible_periods(assumed, 1))} stage-1 candidates "
                        "(26 assumed periods) + stages 2-3 + polish, create_filter defaults, filter_data")
                 ),
-                "parallelism": f"{world} independent recordings, one per GPU, no collectives",
+                "parallelism": parallelism,
                 "filter": {"half_width": int(info.half_width), "taps": int(info.n_taps),
                            "stride_q": int(info.phase_stride or info.stride),
                            "delta_taps": int(info.phase_delta or info.n_delta),
@@ -214,6 +234,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "launch_ms": kern_s * 1e3,
+                "rows_per_launch": rows,
             },
             "breakdown_ms": {
                 "find_period": float(np.mean(timings["find"])) * 1e3,
@@ -222,10 +243,8 @@ def main():
             },
             "period": float(state["period"]),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            chan0 = x[0].cpu().numpy()
-            base, cpu_period = cpu_baseline(chan0)
-            out["cpu_baseline"] = base
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -78,19 +78,6 @@ class ForkMapper:
             _TASK = None
 
 
-class _Synth:
-    def __init__(self, n_samples, period, seed):
-        self.n_samples, self.period, self.seed = n_samples, period, seed
-
-    def __call__(self, chan):
-        # channel `chan` of synth_recording_exact(n_chans, ...): same per-channel streams
-        full_gain = np.random.default_rng(self.seed + 7919)
-        gains = full_gain.uniform(2.0, 10.0, chan + 1)
-        offsets = full_gain.uniform(0.0, self.period, chan + 1)
-        del gains, offsets
-        return synth_recording_exact(chan + 1, self.n_samples, self.period, self.seed)[chan] if chan == 0 else None
-
-
 def _recording(n_chans, n_samples, seed, mapper):
     """``synth_recording_exact`` rows, generated in the pool (one task per channel)."""
     period = FS / F_ART * (1 + 3e-5)

@@ -41,31 +41,38 @@ def synth_recording(n_chans: int, n_samples: int, sampling_freq: float, artefact
 
 def synth_recording_device(n_chans: int, n_samples: int, sampling_freq: float, artefact_freq: float,
                            seed: int = 0, detune: float = 3e-5, dtype=None, device="cuda",
-                           chunk: int = 1 << 22):
+                           chunk: int = 1 << 22, chan_range=None):
     """Same distribution generated directly in HBM (torch RNG for the background; the artefact
-    term is identical to :func:`synth_recording`).  Built in time chunks to bound temporaries."""
+    term is identical to :func:`synth_recording`).  Channel ``c`` is a function of ``(seed, c)`` only
+    -- its own generator stream, gain and phase offset -- so ``chan_range=(lo, hi)`` yields exactly
+    rows ``lo:hi`` of the ``n_chans``-channel recording: the ranks of a channel-sharded run build
+    their blocks of ONE recording without ever holding the rest.  Built in time chunks to bound
+    temporaries."""
     import torch
 
     dtype = dtype or torch.float64
     period = sampling_freq / artefact_freq * (1.0 + detune)
     phases, gains, offsets = _artefact_params(n_chans, period)
+    lo_c, hi_c = (0, n_chans) if chan_range is None else chan_range
+    rows = hi_c - lo_c
     gen = torch.Generator(device=device)
-    gen.manual_seed(1000 + seed)
-    out = torch.empty((n_chans, n_samples), dtype=dtype, device=device)
+    out = torch.empty((rows, n_samples), dtype=dtype, device=device)
+    for c in range(lo_c, hi_c):
+        gen.manual_seed(1000 + seed + 7 * c)
+        out[c - lo_c] = torch.randn(n_samples, dtype=torch.float64, device=device, generator=gen).to(dtype)
     d_ph = torch.from_numpy(phases).to(device)
-    d_gain = torch.from_numpy(gains).to(device)[:, None]
-    d_off = torch.from_numpy(offsets).to(device)[:, None]
+    d_gain = torch.from_numpy(gains[lo_c:hi_c]).to(device)[:, None]
+    d_off = torch.from_numpy(offsets[lo_c:hi_c]).to(device)[:, None]
     w0 = 2.0 * np.pi / period
     for lo in range(0, n_samples, chunk):
         hi = min(lo + chunk, n_samples)
         n = torch.arange(lo, hi, dtype=torch.float64, device=device)[None, :]
         theta = w0 * (n + d_off)
-        art = torch.zeros((n_chans, hi - lo), dtype=torch.float64, device=device)
+        art = torch.zeros((rows, hi - lo), dtype=torch.float64, device=device)
         for k in range(1, N_HARMONICS + 1):
             art += torch.sin(k * theta + d_ph[k - 1]) / k
-        noise = torch.randn((n_chans, hi - lo), dtype=torch.float64, device=device, generator=gen)
-        out[:, lo:hi] = (noise + d_gain * art).to(dtype)
-        del art, noise, theta
+        out[:, lo:hi] = (out[:, lo:hi].to(torch.float64) + d_gain * art).to(dtype)
+        del art, theta
     return out
 
 

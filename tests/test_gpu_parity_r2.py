@@ -296,3 +296,48 @@ def test_config3_find_period_stage_by_stage_vs_oracle():
     np.testing.assert_allclose(val[pick], ref_fin, rtol=1e-9)
     # the accepted period is the best vertex the polish saw
     assert val.min() <= val[np.argmin(np.abs(pts - p.period))] + 1e-15
+
+
+# ---------------------------------------------------------------------------- channel shards (row e)
+def test_sharded_search_reproduces_one_rank_bitwise():
+    """configs[3] on one GPU: four ranks (threads of this process, ``ThreadExchange``) each hold a
+    channel block of ONE recording (blocks of 2, 2, 1, 1 rows) and run ``ShardedPARRM``; the grid
+    errors every rank ends up with, the period and the concatenated ``filter_data`` blocks must be
+    bit-identical to one ``PARRM`` on the whole recording (reference shape of the split:
+    parrm.py:445-454 candidate map, :595-597 channel mean, :861-866 per-channel filter)."""
+    import threading
+
+    from pyparrm_amd import sharding as sh
+
+    x = synth_recording_exact(6, 300_000, 22000.0 / 130.0 * (1 - 1e-4), seed=321)
+    assumed = tuple(22000.0 / 130.0 * (1 + 0.02 * k) for k in range(-2, 3))
+    whole = PARRM(x, 22000.0, 130.0, verbose=False)
+    whole.find_period(assumed_periods=assumed, random_seed=9)
+    whole.create_filter()
+    y_whole = whole.filter_data()
+
+    world = 4
+    results, errors = [None] * world, []
+
+    def rank_main(ex):
+        try:
+            torch.cuda.set_device(0)
+            p = sh.ShardedPARRM(sh.shard_recording(x, ex.rank, world), 22000.0, 130.0, ex, verbose=False)
+            p.find_period(assumed_periods=assumed, random_seed=9)
+            p.create_filter()
+            results[ex.rank] = (p.period, [t["errors"] for t in p._trace[:3]], p.filter_data())
+        except Exception as exc:  # a failing rank would leave the others at the barrier
+            errors.append(exc)
+            ex._barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(ex,)) for ex in sh.ThreadExchange.group(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for rank, (period, stage_errors, _) in enumerate(results):
+        assert period == whole.period, (rank, period, whole.period)
+        for got, want in zip(stage_errors, [t["errors"] for t in whole._trace[:3]]):
+            assert np.array_equal(got, want), rank
+    assert np.array_equal(np.concatenate([r[2] for r in results]), y_whole)

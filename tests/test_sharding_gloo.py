@@ -1,6 +1,11 @@
-"""N>1 path on CPU: world_size-2 ``gloo`` processes.  The shard planning is the product code;
-the arithmetic inside each shard is done by the oracle here (no GPU), and the collectives in this
-file exist only to compare the ranks' results -- the product path has none."""
+"""N>1 path on CPU: world_size-2 ``gloo`` processes.
+
+``test_two_rank_gloo``: the shard arithmetic (index helpers, timing protocol) with the oracle doing the
+work inside each shard.  ``test_sharded_parrm_two_rank_gloo``: the PRODUCT's sharded search
+(``sharding.ShardedPARRM`` + ``TorchExchange`` on a gloo group) end to end -- channel blocks, the
+stage-matrix replication, candidate slices, the replicated Nelder-Mead, per-rank filtering -- with the
+device entry points of ``pyparrm_amd._hip`` replaced by the oracle's arithmetic (there is no GPU here);
+both ranks must land on exactly the period the oracle finds on the unsharded recording."""
 
 import os
 import socket
@@ -95,4 +100,73 @@ def _worker(rank, world, port, out_path):
 def test_two_rank_gloo(tmp_path):
     out = tmp_path / "ok.txt"
     mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
+
+
+def _install_oracle_device(torch, orc):
+    """Replace the device entry points the façade calls by oracle arithmetic on CPU tensors."""
+    from pyparrm_amd import _hip, parrm as facade
+
+    class Plan:
+        def __init__(self, filt, device=None):
+            self.filt, self.device = filt, device
+
+        def apply(self, x, out=None, out_dtype=None):
+            return torch.from_numpy(orc.filter_data_direct(x.numpy(), self.filt))
+
+    def gather(x, idx, scale, ob):
+        d = np.diff(x.numpy().astype(np.float64), axis=1)[:, idx.numpy()]
+        return torch.from_numpy(np.ascontiguousarray(np.clip(d / scale.numpy()[:, None], -ob, ob).T))
+
+    def fit_errors(y, idx, periods, bw, lam, workspace=None, grid_periods=0):
+        rows = np.ascontiguousarray(y.numpy().T)
+        return np.array([orc.fit_error_gathered(p, rows, rows.shape[0], idx.numpy(), bw, lam)
+                         for p in np.asarray(periods, dtype=np.float64).reshape(-1)])
+
+    _hip.require_gpu = lambda: torch
+    _hip.absdiff_mean = lambda x: torch.from_numpy(np.abs(np.diff(x.numpy(), axis=1)).mean(axis=1))
+    _hip.gather_standardise = gather
+    _hip.fit_errors = fit_errors
+    _hip.FitWorkspace = lambda: None
+    _hip.FilterPlan = Plan
+    _hip.to_host_numpy = lambda t: t.numpy()
+    facade.PARRM._device_recording = lambda self, data=None: torch.from_numpy(
+        np.ascontiguousarray(self._data if data is None else data))
+    facade.PARRM._plan_for = lambda self, device: Plan(self._filter)
+
+
+def _sharded_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from oracle import parrm_oracle as orc
+    from pyparrm_amd import sharding as sh
+    from pyparrm_amd.synth import synth_recording_exact
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _install_oracle_device(torch, orc)
+        fs, fa = 1000.0, 130.0
+        x = synth_recording_exact(3, 2600, fs / fa * (1 + 4e-4), seed=77)  # 3 channels: blocks of 2 + 1
+        mine = sh.shard_recording(x, rank, world)
+        p = sh.ShardedPARRM(mine, fs, fa, sh.TorchExchange(dist), verbose=False)
+        p.find_period(random_seed=5)
+        whole = float(orc.find_period(x, fs, fa, random_seed=5))
+        assert float(p.period) == whole, (p.period, whole)
+        assert len(p._trace[0]["errors"]) == len(p._trace[0]["grid"])  # every rank holds the whole grid's errors
+        p.create_filter()
+        y = p.filter_data()
+        lo, hi = sh.channel_shard(3, rank, world)
+        assert np.array_equal(y, orc.filter_data_direct(x, p.filter)[lo:hi])
+        periods = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(periods, torch.tensor([float(p.period)], dtype=torch.float64))  # verification only
+        assert all(float(t) == float(p.period) for t in periods)
+        if rank == 0:
+            open(out_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_parrm_two_rank_gloo(tmp_path):
+    out = tmp_path / "ok.txt"
+    mp.spawn(_sharded_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
