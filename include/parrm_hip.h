@@ -189,6 +189,30 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
                           double lambda, double *h_err, void *d_workspace, size_t workspace_bytes,
                           void *stream);
 
+/* Several independent searches advanced together (per-site period estimation: one PARRM per
+ * recording site, examples/plot_example_dbs_data.py:52-98; each optimiser step of every site is a
+ * handful of candidates on that site's own stage matrix).  Every problem is one
+ * parrm_fit_errors_host call's worth of work -- same kernels, same shapes, so each problem's errors
+ * are bit-identical to that call's -- but the problems are dealt over side streams of the library,
+ * forked from and joined to `stream`, so their small kernels overlap on the device, and the host
+ * waits once.  At most 64 problems and 4096 candidates per call; each problem brings its own
+ * workspace of parrm_fit_workspace_bytes(...) + 16 * n_periods bytes.  Synchronous. */
+typedef struct parrm_fit_problem {
+    const double *d_y;       /* [n_idx][ldy] stage matrix of this search                 */
+    int64_t ldy;
+    const int64_t *d_idx;    /* [n_idx] sample indices                                   */
+    int64_t n_idx, n_chans;
+    const double *h_periods; /* [n_periods] candidates (host)                            */
+    int64_t n_periods;
+    int32_t bw;
+    int32_t reserved;
+    double lambda;
+    double *h_err;           /* [n_periods] errors (host, out)                           */
+    void *d_workspace;
+    size_t workspace_bytes;
+} parrm_fit_problem;
+int parrm_fit_errors_multi(const parrm_fit_problem *problems, int n_problems, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

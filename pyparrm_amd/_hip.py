@@ -42,6 +42,7 @@ SYMBOLS = (
     "parrm_fit_slice_workspace_bytes",
     "parrm_fit_errors_slice",
     "parrm_fit_errors_host",
+    "parrm_fit_errors_multi",
 )
 
 
@@ -62,6 +63,26 @@ class PlanInfo(C.Structure):
         ("phase_groups", C.c_int32),
         ("phase_rows", C.c_int32),
         ("phase_row_slots", C.c_int32),
+    ]
+
+
+class FitProblem(C.Structure):
+    """``parrm_fit_problem`` of include/parrm_hip.h."""
+
+    _fields_ = [
+        ("d_y", C.c_void_p),
+        ("ldy", C.c_int64),
+        ("d_idx", C.c_void_p),
+        ("n_idx", C.c_int64),
+        ("n_chans", C.c_int64),
+        ("h_periods", C.c_void_p),
+        ("n_periods", C.c_int64),
+        ("bw", C.c_int32),
+        ("reserved", C.c_int32),
+        ("lambda_", C.c_double),
+        ("h_err", C.c_void_p),
+        ("d_workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -146,6 +167,8 @@ def lib() -> C.CDLL:
         L.parrm_fit_errors_slice.argtypes = [vp, i64, vp, i64, i64, vp, i64, i64, i32, dbl, vp, vp, C.c_size_t, vp]
         L.parrm_fit_errors_host.restype = i32
         L.parrm_fit_errors_host.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
+        L.parrm_fit_errors_multi.restype = i32
+        L.parrm_fit_errors_multi.argtypes = [C.POINTER(FitProblem), i32, vp]
         if L.parrm_hip_abi_version() != 2:
             raise HipLibraryError("libparrm_hip.so has an unexpected ABI version (rebuild it: make -C pyparrm_amd/csrc)")
         _lib = L
@@ -535,3 +558,62 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
         h_err[:n_per].copy_(d_err[:n_per], non_blocking=True)
         torch.cuda.current_stream().synchronize()
     return h_err[:n_per].numpy().copy()
+
+
+MULTI_MAX_PROBLEMS, MULTI_MAX_PERIODS = 64, 4096
+
+
+def fit_errors_multi(items):
+    """Answer several optimiser steps of independent searches in one call (``parrm_fit_errors_multi``).
+
+    ``items``: sequence of ``(request, workspace)`` -- ``request`` has ``y``, ``d_idx``, ``periods``,
+    ``bandwidth``, ``lambda_`` (a ``parrm.FitRequest``), ``workspace`` is that search's own
+    :class:`FitWorkspace` (the problems run concurrently, so they cannot share scratch).  Returns the
+    list of float64 error vectors, each bit-identical to ``fit_errors`` on the same request."""
+    torch = require_gpu()
+    L = lib()
+    items = list(items)
+    out = [None] * len(items)
+    lo = 0
+    while lo < len(items):
+        hi, total = lo, 0
+        while hi < len(items) and hi - lo < MULTI_MAX_PROBLEMS:
+            n = int(np.asarray(items[hi][0].periods).size)
+            if n > MULTI_MAX_PERIODS:
+                break
+            if total + n > MULTI_MAX_PERIODS:
+                break
+            total += n
+            hi += 1
+        if hi == lo:  # a request too large for the hand-off block: the plain path
+            req, ws = items[lo]
+            out[lo] = fit_errors(req.y, req.d_idx, req.periods, req.bandwidth, req.lambda_, ws)
+            lo += 1
+            continue
+        problems = (FitProblem * (hi - lo))()
+        keep = []
+        device = items[lo][0].y.device
+        for k, (req, ws) in enumerate(items[lo:hi]):
+            if req.y.device != device:
+                raise ValueError("fit_errors_multi: all stage matrices of one call must be on one device")
+            periods = np.ascontiguousarray(np.asarray(req.periods, dtype=np.float64).reshape(-1))
+            n_idx, n_chans = req.y.shape
+            n_per = periods.shape[0]
+            nbytes = ws.nbytes(n_idx, n_chans, n_per, req.bandwidth) + 16 * n_per
+            if nbytes == 16 * n_per:
+                raise HipLibraryError("parrm_fit_workspace_bytes rejected the problem shape")
+            buf = ws.get(nbytes, device)
+            err = np.empty(n_per, dtype=np.float64)
+            keep.append((periods, buf, err))
+            q = problems[k]
+            q.d_y, q.ldy, q.d_idx = req.y.data_ptr(), req.y.stride(0), req.d_idx.data_ptr()
+            q.n_idx, q.n_chans = n_idx, n_chans
+            q.h_periods, q.n_periods = periods.ctypes.data, n_per
+            q.bw, q.reserved, q.lambda_ = int(req.bandwidth), 0, float(req.lambda_)
+            q.h_err, q.d_workspace, q.workspace_bytes = err.ctypes.data, buf.data_ptr(), nbytes
+            out[lo + k] = err
+        with _on_device(torch, device):
+            check(L.parrm_fit_errors_multi(problems, hi - lo, _stream_ptr(torch)), "parrm_fit_errors_multi")
+        del keep
+        lo = hi
+    return out

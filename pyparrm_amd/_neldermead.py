@@ -144,6 +144,24 @@ class _Start:
         return np.array([self.sim[0]], dtype=np.float64), float(fmin_), self.iterations, self.fcalls
 
 
+def fmin_lockstep_requests(starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None):
+    """Generator form of :func:`fmin_lockstep`: yields the float64 array of abscissae of each batch
+    and expects their objective values to be sent back; returns (``StopIteration.value``) the list of
+    ``(xopt[1], fopt, iterations, funcalls)``.  Lets a caller advance several independent searches
+    together and evaluate all their batches in one device call."""
+    runs = [_Start(x0, xtol, ftol, maxiter, maxfun) for x0 in starts]
+    while True:
+        active = [run for run in runs if not run.done]
+        if not active:
+            break
+        points = sorted({x for run in active for x in run.wanted() if x == x})
+        values = yield np.array(points, dtype=np.float64)
+        table = dict(zip(points, np.asarray(values, dtype=np.float64).tolist()))
+        for run in active:
+            run.advance(table)
+    return [run.result() for run in runs]
+
+
 def fmin_lockstep(objective_batch, starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None):
     """Run one SciPy-equivalent ``fmin`` per entry of ``starts``, advancing all of them together.
 
@@ -151,14 +169,10 @@ def fmin_lockstep(objective_batch, starts, xtol=1e-4, ftol=1e-4, maxiter=None, m
     a batch.  Returns a list of ``(xopt[1], fopt, iterations, funcalls)`` in the order of
     ``starts`` -- what ``fmin(..., full_output=True)[:4]`` returns.
     """
-    runs = [_Start(x0, xtol, ftol, maxiter, maxfun) for x0 in starts]
-    while True:
-        active = [run for run in runs if not run.done]
-        if not active:
-            break
-        points = sorted({x for run in active for x in run.wanted() if x == x})
-        values = np.asarray(objective_batch(np.array(points, dtype=np.float64)), dtype=np.float64)
-        table = dict(zip(points, values.tolist()))
-        for run in active:
-            run.advance(table)
-    return [run.result() for run in runs]
+    requests = fmin_lockstep_requests(starts, xtol, ftol, maxiter, maxfun)
+    try:
+        points = next(requests)
+        while True:
+            points = requests.send(objective_batch(points))
+    except StopIteration as stop:
+        return stop.value

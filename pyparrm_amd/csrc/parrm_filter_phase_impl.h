@@ -799,12 +799,39 @@ static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs a, PhaseGeom
         default: parrm::set_error("filter: unsupported rows-per-thread %d", g.rows); return PARRM_ERR_INVALID;
     }
     const int ngr = g.n_groups * g.rows;
-    // stretch: ~256K samples in whole iterations (fewer ring prologues; 128K measured 1-1.5 % slower, 512K 2 % slower); shrink while the grid would not fill the chip
+    // Stretch length.  A stretch costs its samples plus a fixed prologue (the ring fill of 2*hw + NG*R*q
+    // samples and one full tap evaluation per thread: ~16 K samples' worth, fitted on 64 x 1 M).  512
+    // workgroups are resident at once (two per CU), so a launch runs in ceil(blocks / 512) rounds of one
+    // stretch each.  Long recordings: ~256 K-sample stretches (128 K measured 1-1.5 % slower, 512 K 2 %
+    // slower: with many rounds the tail evens out, and longer stretches only lose balance).  Short ones
+    // (e.g. 64 ch x 1 M): pick the stretch count per channel that minimises rounds x (stretch + prologue)
+    // -- round 1 always cut down to >= 2048 workgroups, i.e. 31 K-sample stretches at 64 x 1 M, where the
+    // prologue was a third of the work.
     int64_t target = 262144;
     if (const char *env = getenv("PARRM_STRETCH_SAMPLES")) target = std::max<int64_t>(atoll(env), g.q);  // tuning knob
     int64_t rows = std::max<int64_t>(ngr, (target / g.q) / ngr * ngr);
     auto blocks_for = [&](int64_t r) { return a.n_chans * ((a.out_len + r * g.q - 1) / (r * g.q)); };
-    while (rows > 4 * ngr && blocks_for(rows) < 2048) rows = std::max<int64_t>(ngr, (rows / 2) / ngr * ngr);
+    if (blocks_for(rows) < 4096 && !getenv("PARRM_STRETCH_SAMPLES")) {
+        const double prologue = 16384.0;
+        const int64_t resident = 512;
+        double best = 1e300;
+        int64_t best_rows = rows;
+        const int64_t max_stretches = std::max<int64_t>(1, a.out_len / (static_cast<int64_t>(4) * ngr * g.q));
+        for (int64_t per_chan = 1; per_chan <= std::min<int64_t>(max_stretches, 4096); ++per_chan) {
+            const int64_t r = ((a.out_len + per_chan - 1) / per_chan + g.q - 1) / g.q;      // rows per stretch
+            const int64_t rr = (r + ngr - 1) / ngr * ngr;                                     // whole iterations
+            const int64_t blocks = blocks_for(rr);
+            const int64_t rounds = (blocks + resident - 1) / resident;
+            // a last, partly filled round costs a whole round; beyond a few rounds the dispatcher evens things out
+            const double cost = static_cast<double>(rounds) * (static_cast<double>(rr * g.q) + prologue);
+            if (cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                best_rows = rr;
+            }
+            if (blocks > 8192) break;
+        }
+        rows = best_rows;
+    }
     a.stretch_len = rows * g.q;
     a.n_stretch = (a.out_len + a.stretch_len - 1) / a.stretch_len;
     const int64_t blocks = a.n_chans * a.n_stretch;

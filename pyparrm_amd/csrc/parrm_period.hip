@@ -810,20 +810,41 @@ __global__ void __launch_bounds__(64) fit_publish_kernel(const double *err, int 
 
 struct HostStage {
     static constexpr int64_t kCap = 4096;  // candidates per staged call; larger batches use the copy path
-    double *h = nullptr;                   // [kCap] (unused) | [kCap] errors | flag
+    static constexpr int kMaxProblems = 64;  // problems per parrm_fit_errors_multi call
+    static constexpr int kStreams = 8;       // side streams the problems of one call are dealt over
+    double *h = nullptr;                   // [kCap] periods (multi) | [kCap] errors | flag | [kMaxProblems] flags (multi)
     double *d = nullptr;                   // the same block through the device's mapping
     int device = -1;
     unsigned long long seq = 0;
+    hipStream_t side[kStreams] = {};
+    hipEvent_t fork = nullptr, join[kStreams] = {};
     void release() {
+        for (int i = 0; i < kStreams; ++i) {
+            if (join[i]) (void)hipEventDestroy(join[i]);
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+            join[i] = nullptr;
+            side[i] = nullptr;
+        }
+        if (fork) (void)hipEventDestroy(fork);
+        fork = nullptr;
         if (h) (void)hipHostFree(h);
         h = d = nullptr;
         device = -1;
+    }
+    bool streams_ready() {
+        if (fork) return true;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        for (int i = 0; i < kStreams; ++i) {
+            if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        return true;
     }
     bool ready(int dev) {
         if (h && device == dev) return true;
         release();
         void *p = nullptr;
-        if (hipHostMalloc(&p, (2 * kCap + 8) * sizeof(double), hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostMalloc(&p, (2 * kCap + 8 + kMaxProblems) * sizeof(double), hipHostMallocMapped) != hipSuccess) return false;
         void *dp = nullptr;
         if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
             (void)hipHostFree(p);
@@ -832,7 +853,7 @@ struct HostStage {
         h = static_cast<double *>(p);
         d = static_cast<double *>(dp);
         device = dev;
-        *reinterpret_cast<volatile unsigned long long *>(h + 2 * kCap) = 0;
+        for (int i = 0; i < 8 + kMaxProblems; ++i) *reinterpret_cast<volatile unsigned long long *>(h + 2 * kCap + i) = 0;
         return true;
     }
 };
@@ -1068,6 +1089,83 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
     if (rc != PARRM_OK) return rc;
     PARRM_HIP_CHECK(hipMemcpyAsync(h_err, d_err, n_periods * sizeof(double), hipMemcpyDeviceToHost, s));
     PARRM_HIP_CHECK(hipStreamSynchronize(s));
+    return PARRM_OK;
+}
+
+int parrm_fit_errors_multi(const parrm_fit_problem *problems, int n_problems, void *stream) {
+    PARRM_REQUIRE(problems && n_problems > 0 && n_problems <= HostStage::kMaxProblems,
+                  "fit_errors_multi: 1..%d problems per call", HostStage::kMaxProblems);
+    int64_t total = 0;
+    for (int p = 0; p < n_problems; ++p) {
+        const parrm_fit_problem &q = problems[p];
+        PARRM_REQUIRE(q.h_periods && q.h_err && q.d_workspace && q.n_periods > 0, "fit_errors_multi: problem %d: NULL or empty", p);
+        const size_t inner = parrm_fit_workspace_bytes(q.n_idx, q.n_chans, q.n_periods, q.bw);
+        PARRM_REQUIRE(inner != 0, "fit_errors_multi: problem %d: bad shape", p);
+        if (q.workspace_bytes < inner + 2 * static_cast<size_t>(q.n_periods) * sizeof(double)) {
+            parrm::set_error("fit_errors_multi: problem %d: workspace too small", p);
+            return PARRM_ERR_WORKSPACE;
+        }
+        total += q.n_periods;
+    }
+    PARRM_REQUIRE(total <= HostStage::kCap, "fit_errors_multi: more than %lld candidates in one call", (long long)HostStage::kCap);
+    int dev = 0;
+    PARRM_HIP_CHECK(hipGetDevice(&dev));
+    HostStage &st = thread_stage();
+    if (!st.ready(dev) || !st.streams_ready()) {
+        parrm::set_error("fit_errors_multi: cannot allocate the host hand-off block / side streams");
+        return PARRM_ERR_HIP;
+    }
+    hipStream_t s = parrm::as_stream(stream);
+    const unsigned long long seq = ++st.seq;
+    volatile unsigned long long *h_flags = reinterpret_cast<volatile unsigned long long *>(st.h + 2 * HostStage::kCap + 8);
+    volatile unsigned long long *d_flags = reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap + 8);
+    // fork: every side stream starts behind what is already queued on the caller's stream (the stage
+    // matrices were written there)
+    const int used = n_problems < HostStage::kStreams ? n_problems : HostStage::kStreams;
+    PARRM_HIP_CHECK(hipEventRecord(st.fork, s));
+    for (int k = 0; k < used; ++k) PARRM_HIP_CHECK(hipStreamWaitEvent(st.side[k], st.fork, 0));
+    int64_t off = 0;
+    for (int p = 0; p < n_problems; ++p) {
+        const parrm_fit_problem &q = problems[p];
+        hipStream_t sp = st.side[p % HostStage::kStreams];
+        const size_t inner = parrm_fit_workspace_bytes(q.n_idx, q.n_chans, q.n_periods, q.bw);
+        double *d_per = reinterpret_cast<double *>(static_cast<char *>(q.d_workspace) + inner);
+        double *d_err = d_per + q.n_periods;
+        std::memcpy(st.h + off, q.h_periods, q.n_periods * sizeof(double));  // page-locked staging: a true async copy
+        PARRM_HIP_CHECK(hipMemcpyAsync(d_per, st.h + off, q.n_periods * sizeof(double), hipMemcpyHostToDevice, sp));
+        const int rc = parrm_fit_errors(q.d_y, q.ldy, q.d_idx, q.n_idx, q.n_chans, d_per, q.n_periods, q.bw, q.lambda,
+                                        d_err, q.d_workspace, inner, sp);
+        if (rc != PARRM_OK) return rc;
+        hipLaunchKernelGGL(fit_publish_kernel, dim3(1), dim3(64), 0, sp, d_err, static_cast<int>(q.n_periods),
+                           st.d + HostStage::kCap + off, d_flags + p, seq);
+        PARRM_HIP_CHECK(hipGetLastError());
+        off += q.n_periods;
+    }
+    // join: later work on the caller's stream stays ordered behind the side streams
+    for (int k = 0; k < used; ++k) {
+        PARRM_HIP_CHECK(hipEventRecord(st.join[k], st.side[k]));
+        PARRM_HIP_CHECK(hipStreamWaitEvent(s, st.join[k], 0));
+    }
+    off = 0;
+    for (int p = 0; p < n_problems; ++p) {
+        hipStream_t sp = st.side[p % HostStage::kStreams];
+        for (unsigned spins = 0; h_flags[p] != seq; ++spins) {
+            if ((spins & 0xffff) == 0xffff) {
+                const hipError_t e = hipStreamQuery(sp);
+                if (e == hipSuccess) {
+                    if (h_flags[p] == seq) break;
+                    PARRM_HIP_CHECK(hipStreamSynchronize(sp));
+                    PARRM_REQUIRE(h_flags[p] == seq, "fit_errors_multi: a side stream drained without publishing its errors");
+                    break;
+                }
+                if (e != hipErrorNotReady) return parrm::hip_fail(e, "fit_errors_multi: side stream");
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(problems[p].h_err, st.h + HostStage::kCap + off, problems[p].n_periods * sizeof(double));
+        off += problems[p].n_periods;
+    }
     return PARRM_OK;
 }
 

@@ -32,7 +32,7 @@ from multiprocessing import cpu_count
 
 import numpy as np
 from . import _hip
-from ._neldermead import fmin_lockstep
+from ._neldermead import fmin_lockstep_requests
 
 _PERIOD_FAILURE = (
     "The period cannot be estimated from the data. Check that your data "
@@ -349,14 +349,17 @@ class PARRM:
         here; ``sharding.ShardedPARRM`` cuts the grid into per-rank slices instead."""
         return _hip.fit_errors(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, workspace)
 
-    def _optimise_period_estimate(self) -> None:
-        """Three coarse-to-fine stages + an un-regularised polish (parrm.py:282-325)."""
+    def _search_requests(self):
+        """The period search (parrm.py:282-325: three coarse-to-fine stages + an un-regularised
+        polish) as a generator of objective evaluations: yields :class:`FitRequest` objects, expects
+        the float64 error vector of each to be sent back, and leaves ``_period`` / ``_trace`` set when
+        it finishes.  ``find_period`` answers the requests one by one; :func:`find_period_batched`
+        advances several searches together and answers all their small requests in one device call."""
         rng = np.random.default_rng(self._random_seed)
         estimate = self._assumed_periods
         lengths = np.unique(
             [int(np.min((self._search_span[2], n))) for n in _STAGE_LENGTHS]
         )
-        ws = _hip.FitWorkspace()
         trace = []
         stage = None
         for run, (use_n, ignore, bandwidth) in enumerate(
@@ -366,18 +369,11 @@ class PARRM:
             bandwidth = int(np.min((bandwidth, indices.shape[0] // 4)))
             y, d_idx = self._stage_matrix(indices)
             stage = (y, d_idx)
-
-            evals = []
-
-            def objective(periods, _y=y, _i=d_idx, _bw=bandwidth, _log=evals):
-                errors = _hip.fit_errors(_y, _i, periods, _bw, _STAGE_LAMBDA, ws)
-                _log.append((np.array(periods, dtype=np.float64), errors))
-                return errors
-
             grid = self._get_possible_periods(estimate, run)
-            errors = self._grid_errors(y, d_idx, grid, bandwidth, ws)
+            errors = yield FitRequest(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, True)
             ranked, ranked_errors = _rank_candidates(grid, errors)
-            estimate = _refine_candidates(ranked, ranked_errors, objective)
+            evals = []
+            estimate = yield from _refine_candidates(ranked, ranked_errors, y, d_idx, bandwidth, evals)
             trace.append(
                 {"indices": indices, "bandwidth": bandwidth, "grid": grid, "errors": errors,
                  "estimate": float(estimate[0]), "refine_evals": evals}
@@ -388,17 +384,28 @@ class PARRM:
         # final polish: lambda = 0, bandwidth 20 *unclipped*, last stage's indices (parrm.py:524-550)
         y, d_idx = stage
         final_bw = _STAGE_BANDWIDTHS[-1]
-
         final_evals = []
-
-        def final_objective(periods):
-            errors = _hip.fit_errors(y, d_idx, periods, final_bw, 0.0, ws)
-            final_evals.append((np.array(periods, dtype=np.float64), errors))
-            return errors
-
-        self._period = fmin_lockstep(final_objective, [estimate[0]])[0][0][0]
+        result = yield from _fmin_requests([estimate[0]], y, d_idx, final_bw, 0.0, final_evals)
+        self._period = result[0][0][0]
         trace.append({"final_bandwidth": final_bw, "final_evals": final_evals})
         self._trace = trace
+
+    def _answer(self, request, workspace) -> np.ndarray:
+        """Evaluate one request of this object's own search."""
+        if request.is_grid:
+            return self._grid_errors(request.y, request.d_idx, request.periods, request.bandwidth, workspace)
+        return _hip.fit_errors(request.y, request.d_idx, request.periods, request.bandwidth, request.lambda_, workspace)
+
+    def _optimise_period_estimate(self) -> None:
+        """Drive :meth:`_search_requests` to the end, one device call per request."""
+        ws = _hip.FitWorkspace()
+        requests = self._search_requests()
+        try:
+            request = next(requests)
+            while True:
+                request = requests.send(self._answer(request, ws))
+        except StopIteration:
+            pass
 
     def _get_centre_indices(self, use_n_samples, ignore_portion, random_state) -> np.ndarray:
         """Sample indices for one stage (parrm.py:327-374): a contiguous centre block, or -- when
@@ -690,14 +697,99 @@ def _rank_candidates(periods: np.ndarray, errors: np.ndarray):
     return periods, errors
 
 
-def _refine_candidates(periods: np.ndarray, errors: np.ndarray, objective) -> tuple:
+class FitRequest:
+    """One objective evaluation of a period search: the candidates ``periods`` on the stage matrix
+    ``y`` / sample indices ``d_idx`` (device tensors) with harmonics up to ``bandwidth`` and
+    regulariser weight ``lambda_``.  ``is_grid`` marks a whole stage grid (hundreds to thousands of
+    candidates: throughput-bound) as opposed to one optimiser step (<= 25: latency-bound)."""
+
+    __slots__ = ("y", "d_idx", "periods", "bandwidth", "lambda_", "is_grid")
+
+    def __init__(self, y, d_idx, periods, bandwidth, lambda_, is_grid):
+        self.y, self.d_idx, self.periods = y, d_idx, periods
+        self.bandwidth, self.lambda_, self.is_grid = bandwidth, lambda_, is_grid
+
+
+def _fmin_requests(starts, y, d_idx, bandwidth, lambda_, log):
+    """Lock-step Nelder-Mead from ``starts`` as a generator of :class:`FitRequest` (one per optimiser
+    step); returns ``fmin_lockstep``'s result list.  Every evaluation is appended to ``log``."""
+    steps = fmin_lockstep_requests(starts)
+    try:
+        points = next(steps)
+        while True:
+            errors = yield FitRequest(y, d_idx, points, bandwidth, lambda_, False)
+            log.append((points, errors))
+            points = steps.send(errors)
+    except StopIteration as stop:
+        return stop.value
+
+
+def _refine_candidates(periods: np.ndarray, errors: np.ndarray, y, d_idx, bandwidth, log):
     """Nelder-Mead (SciPy ``fmin`` defaults) from the best <= 5 candidates; keep the overall
     arg-min (parrm.py:467-522).  ``errors`` may be longer than ``periods`` (non-finite tail).
     The starts are independent in the reference too (an ordered map, :510-517); here they advance
-    in lock-step so that each device batch serves all of them (``_neldermead.fmin_lockstep``)."""
+    in lock-step so that each device batch serves all of them (``_neldermead``).  Generator: see
+    :func:`_fmin_requests`; returns the 1-tuple holding the refined estimate."""
     n_starts = int(np.min((5, periods.shape[0])))
-    results = fmin_lockstep(objective, [periods[i] for i in range(n_starts)])
+    results = yield from _fmin_requests([periods[i] for i in range(n_starts)], y, d_idx, bandwidth,
+                                        _STAGE_LAMBDA, log)
     for i, (xopt, fopt, _, _) in enumerate(results):
         periods[i] = xopt[0]
         errors[i] = fopt
     return (periods[errors.argmin()],)
+
+
+def find_period_batched(parrms, search_samples=None, assumed_periods=None, outlier_boundary=3.0,
+                        random_seed=None, n_jobs=1) -> None:
+    """``find_period`` for several ``PARRM`` objects at once -- per-site period estimation
+    (examples/plot_example_dbs_data.py:52-98 builds one ``PARRM`` per recording site and calls
+    ``find_period()`` on each): same arguments as :meth:`PARRM.find_period`, applied to every object.
+
+    The searches advance together.  Each one's stage grids go to the device one after another (they
+    fill the chip on their own), but the Nelder-Mead steps -- ~90 dependent, latency-bound evaluations
+    per search -- of ALL searches are answered by one ``parrm_fit_errors_multi`` call per step, their
+    small kernels overlapping on side streams.  Every evaluation is the single-instance evaluation
+    (same kernels, same shapes), so each object ends with exactly the period its own
+    ``find_period()`` would have found."""
+    parrms = list(parrms)
+    for p in parrms:
+        if not isinstance(p, PARRM):
+            raise TypeError("`parrms` must be PARRM objects.")
+        p._say("\nFinding the artefact period...")
+        p._reset_result_attrs()
+        p._check_sort_find_stim_period_inputs(search_samples, assumed_periods, outlier_boundary, random_seed, n_jobs)
+        p._in_call = False
+        if not p.cache_on_device:
+            p._d_data = p._d_data_src = None
+    try:
+        searches, pending, spaces = [], [], []
+        grid_ws = _hip.FitWorkspace()
+        for p in parrms:
+            p._standardise_data()
+            search = p._search_requests()
+            searches.append(search)
+            pending.append(next(search))
+            spaces.append(_hip.FitWorkspace())
+        active = list(range(len(parrms)))
+        while active:
+            answers = {}
+            steps = [i for i in active if not pending[i].is_grid]
+            for i in active:
+                if pending[i].is_grid:
+                    answers[i] = parrms[i]._answer(pending[i], grid_ws)
+            if steps:
+                for i, errors in zip(steps, _hip.fit_errors_multi([(pending[i], spaces[i]) for i in steps])):
+                    answers[i] = errors
+            still = []
+            for i in active:
+                try:
+                    pending[i] = searches[i].send(answers[i])
+                    still.append(i)
+                except StopIteration:
+                    pass
+            active = still
+    finally:
+        for p in parrms:
+            p._end_call()
+    for p in parrms:
+        p._say("    ... Artefact period found\n")

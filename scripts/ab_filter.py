@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=["4,2", "2,4"])
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--flags", nargs="*", default=None, help="PARRM_DEBUG_FLAGS values to A/B instead of shapes")
+    ap.add_argument("--stretch", nargs="*", default=None, help="PARRM_STRETCH_SAMPLES values to A/B (0 = the plan's own choice)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--lib", default=None, help="load this build of libparrm_hip.so instead of the in-tree one")
     args = ap.parse_args()
 
@@ -32,12 +34,18 @@ def main():
     _hip.require_gpu()
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn((args.chans, args.samples), dtype=torch.float64, device="cuda", generator=g)
+    if args.dtype == "f32":
+        x = x.to(torch.float32)
     y = torch.empty_like(x)
     p = PARRM(np.zeros((1, args.samples)), 22000.0, 130.0, verbose=False)
     p._period = np.float64(22000.0 / 130.0 * (1 + 3e-5))
     p.create_filter()
     arms = []
-    if args.flags:
+    if args.stretch:
+        plan = _hip.FilterPlan(p.filter)
+        for v in args.stretch:
+            arms.append((f"stretch={v}", plan, {} if v == "0" else {"PARRM_STRETCH_SAMPLES": v}))
+    elif args.flags:
         plan = _hip.FilterPlan(p.filter)
         plan.set_kernel(3)
         for f in args.flags:
@@ -64,7 +72,7 @@ def main():
                 os.environ.pop(k, None)
             if rnd:  # round 0 warms up
                 times[name].append(e0.elapsed_time(e1))
-    nbytes = 2 * x.numel() * 8
+    nbytes = 2 * x.numel() * x.element_size()
     for name, ts in times.items():
         med = float(np.median(ts))
         print(f"{name}: median {med:.3f} ms  min {min(ts):.3f}  max {max(ts):.3f}  -> {nbytes / med / 1e6:.0f} GB/s")

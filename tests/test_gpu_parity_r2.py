@@ -341,3 +341,93 @@ def test_sharded_search_reproduces_one_rank_bitwise():
         for got, want in zip(stage_errors, [t["errors"] for t in whole._trace[:3]]):
             assert np.array_equal(got, want), rank
     assert np.array_equal(np.concatenate([r[2] for r in results]), y_whole)
+
+
+# ---------------------------------------------------------------------------- batched searches (f2)
+def test_find_period_batched_equals_single_instances(golden):
+    """examples/plot_example_dbs_data.py:52-98 (ECoG + LFP together, ECoG alone, LFP alone) as ONE batched
+    call: every object's period must equal -- bit for bit -- its own ``find_period()`` result, and the
+    reference's fixture."""
+    from pyparrm_amd import find_period_batched
+
+    g = golden("r2_per_site.npz")
+    x = np.load(get_example_data_paths("ecog_lfp_data"))
+    groups = (("both", [0, 1]), ("ecog", [0]), ("lfp", [1]))
+    singles = []
+    for _, rows in groups:
+        p = PARRM(x[rows], 1000, 130, verbose=False)
+        p.find_period(random_seed=44)
+        singles.append(p.period)
+    batch = [PARRM(x[rows], 1000, 130, verbose=False) for _, rows in groups]
+    find_period_batched(batch, random_seed=44)
+    for (name, _), p, single in zip(groups, batch, singles):
+        assert p.period == single, (name, p.period, single)
+        ref = float(g[name])
+        assert abs(p.period - ref) <= PERIOD_RTOL * ref
+        assert isinstance(p.period, np.float64)
+    # the objects are ordinary PARRM objects afterwards
+    batch[1].create_filter(period_half_width=0.02, filter_half_width=5000)
+    y = batch[1].filter_data()
+    ref_y = orc.filter_data_direct(x[[0]], batch[1].filter)
+    assert np.abs(y - ref_y).max() <= 1e-10 * np.abs(ref_y).max()
+
+
+def test_find_period_batched_mixed_lengths_and_failures():
+    """Searches of different depth in one batch (recordings shorter than the stage lengths finish after
+    one or two stages), against the reference's periods; and the reference's error contract: a search
+    that cannot succeed raises the reference's ValueError (parrm.py:459-463)."""
+    from pyparrm_amd import find_period_batched
+
+    cases = [c for c in R2["short"] + R2["fuzz"][:9] if c["random_seed"] is not None]
+    # one seed per call (the reference's signature): group the cases by seed
+    by_seed = {}
+    for c in cases:
+        by_seed.setdefault((c["random_seed"], c["fs"], c["fa"]), []).append(c)
+    checked = 0
+    for (seed, fs, fa), group in by_seed.items():
+        batch = [PARRM(_case_recording(c), fs, fa, verbose=False) for c in group]
+        find_period_batched(batch, random_seed=seed)
+        for c, p in zip(group, batch):
+            assert abs(p.period - c["ref_period"]) <= PERIOD_RTOL * c["ref_period"], c["tag"]
+            checked += 1
+    assert checked == len(cases)
+    bad = np.random.default_rng(0).standard_normal((1, 3000))
+    bad[0, 100] = np.nan
+    good = synth_recording_exact(1, 3000, 7.7, seed=1)
+    with pytest.raises(ValueError, match="The period cannot be estimated from the data."):
+        find_period_batched([PARRM(good, 1000, 130, verbose=False), PARRM(bad, 1000, 130, verbose=False)], random_seed=1)
+    with pytest.raises(TypeError, match="must be PARRM objects"):
+        find_period_batched([good])
+
+
+def test_find_period_batched_amortises_the_optimiser_steps():
+    """Eight single-channel sites: the batched call must beat eight sequential searches (the point of
+    batching is the ~90 dependent optimiser steps per search, not the arithmetic)."""
+    import time
+
+    from pyparrm_amd import find_period_batched
+
+    sites = [synth_recording_exact(1, 60000, 1000.0 / 130.0 * (1 + 1e-4 * k), seed=40 + k) for k in range(8)]
+
+    def sequential():
+        out = []
+        for x in sites:
+            p = PARRM(x, 1000, 130, verbose=False)
+            p.find_period(random_seed=3)
+            out.append(p.period)
+        return out
+
+    def batched():
+        ps = [PARRM(x, 1000, 130, verbose=False) for x in sites]
+        find_period_batched(ps, random_seed=3)
+        return [p.period for p in ps]
+
+    sequential(), batched()  # warm: plans, workspaces, side streams
+    t0 = time.perf_counter()
+    a = sequential()
+    t1 = time.perf_counter()
+    b = batched()
+    t2 = time.perf_counter()
+    assert a == b
+    print(f"\n8 sites: sequential {1e3 * (t1 - t0):.1f} ms, batched {1e3 * (t2 - t1):.1f} ms")
+    assert t2 - t1 < 0.8 * (t1 - t0)
