@@ -48,6 +48,8 @@ _STAGE_LENGTHS = (5000, 10000, 25000)
 _STAGE_IGNORE = (0.0, 0.0, 0.95)
 _STAGE_BANDWIDTHS = (5, 10, 20)
 _STAGE_LAMBDA = 1.0
+# stage grids up to this many candidates join the optimiser steps in find_period_batched's shared call
+_SMALL_GRID = 512
 # above this size a host recording is streamed through the device instead of cached on it
 _DEVICE_CACHE_BYTES = 96 << 30
 
@@ -320,26 +322,63 @@ class PARRM:
 
         self._n_jobs = _checked_n_jobs(n_jobs)
 
+    def _streams_from_host(self) -> bool:
+        """True when the recording stays on the host (a memory-mapped file, or an array larger than
+        the device cache budget): ``find_period`` then streams its one full pass in time chunks and
+        gathers the <= 25 001 stage columns on the host, ``filter_data`` streams as well."""
+        data = self._data
+        return isinstance(data, np.ndarray) and (isinstance(data, np.memmap) or data.nbytes > _DEVICE_CACHE_BYTES)
+
     def _standardise_data(self) -> None:
         """Device statistics pass for parrm.py:272-280.
 
         Only ``scale[c] = mean|diff|`` is produced (one HBM read of the recording); the
         standardised array itself is never materialised -- each stage gathers and scales the
         <= 25 001 columns it consumes (``_stage_matrix``)."""
-        x = self._device_recording()
-        if x.shape[1] < 2:
+        if self._n_samples < 2:
             raise ValueError("`data` must have at least 2 samples to estimate a period.")
         kind = getattr(self._data, "dtype", None)
         if isinstance(self._data, np.ndarray) and kind is not None and not np.issubdtype(kind, np.floating):
             # the reference's in-place divide raises for integer recordings (parrm.py:275)
             raise TypeError("`data` must have a floating-point dtype to estimate the period.")
-        self._d_scale = _hip.absdiff_mean(x)
+        if self._streams_from_host():
+            self._d_scale = self._streamed_absdiff_mean()
+            return
+        self._d_scale = _hip.absdiff_mean(self._device_recording())
+
+    def _streamed_absdiff_mean(self, chunk_bytes: int = 1 << 30):
+        """``mean|diff|`` per channel of a host-resident recording, one time chunk on the device at a
+        time: chunk k contributes ``mean_k * n_k`` (consecutive chunks share one sample, so every
+        difference is counted once); the chunk sums are added in float64 in chunk order."""
+        torch = _hip.require_gpu()
+        data = self._data
+        step = max(int(chunk_bytes // (data.dtype.itemsize * self._n_chans)), 2)
+        total = None
+        for lo in range(0, self._n_samples - 1, step):
+            hi = min(lo + step, self._n_samples - 1)  # differences lo .. hi-1 need samples lo .. hi
+            host = np.ascontiguousarray(data[:, lo:hi + 1])
+            if host.dtype not in (np.float32, np.float64):
+                host = host.astype(np.float64)
+            part = _hip.absdiff_mean(torch.from_numpy(host).cuda()) * float(hi - lo)
+            total = part if total is None else total + part
+        return total / float(self._n_samples - 1)
 
     def _stage_matrix(self, indices: np.ndarray):
         torch = _hip.require_gpu()
-        x = self._device_recording()
         if indices.shape[0] == 0 or indices[0] < 0 or indices[-1] >= self._n_samples - 1:
             raise IndexError("period-search sample indices fall outside the differenced recording")
+        if self._streams_from_host():
+            # gather the two samples of every difference on the host and let the device kernel do the
+            # same arithmetic on the compact array: x'[c, 2j] = x[c, idx_j], x'[c, 2j+1] = x[c, idx_j + 1]
+            pairs = np.empty((self._n_chans, 2 * indices.shape[0]), dtype=self._data.dtype)
+            pairs[:, 0::2] = self._data[:, indices]
+            pairs[:, 1::2] = self._data[:, indices + 1]
+            x = torch.from_numpy(pairs).cuda()
+            compact = torch.arange(0, 2 * indices.shape[0], 2, dtype=torch.int64, device=x.device)
+            y = _hip.gather_standardise(x, compact, self._d_scale, self._outlier_boundary)
+            d_idx = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64)).to(x.device)
+            return y, d_idx
+        x = self._device_recording()
         d_idx = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64)).to(x.device)
         y = _hip.gather_standardise(x, d_idx, self._d_scale, self._outlier_boundary)
         return y, d_idx
@@ -594,8 +633,8 @@ class PARRM:
             )
         data = self._check_sort_filter_data_inputs(data)
         try:
-            if isinstance(data, np.ndarray) and data.nbytes > _DEVICE_CACHE_BYTES:
-                filtered = self._plan_for(None).apply_host(data)
+            if isinstance(data, np.ndarray) and (isinstance(data, np.memmap) or data.nbytes > _DEVICE_CACHE_BYTES):
+                filtered = self._plan_for(None).apply_host(np.ascontiguousarray(data))
             else:
                 x = self._device_recording(data)
                 y = self._plan_for(x.device).apply(x)
@@ -605,6 +644,23 @@ class PARRM:
         self._filtered_data = filtered
         self._say("    ... Data filtered\n")
         return self._filtered_data
+
+    def online(self, n_chans=None, dtype=None, out_dtype=np.float64, device=None):
+        """Stateful block-by-block filtering with the current filter (``streaming.OnlineFilter``):
+        push consecutive blocks, receive every output that has become computable.  Zero latency for
+        the one-sided filter that only reaches earlier samples (``filter_direction="future"``, the
+        taps ``w > 0`` of parrm.py:819-820)."""
+        if self._filter is None:
+            raise ValueError(
+                "The filter has not yet been created. The `create_filter` method must "
+                "be called first."
+            )
+        from .streaming import OnlineFilter
+
+        if dtype is None:
+            dtype = np.float32 if str(getattr(self._data, "dtype", "")).endswith("float32") else np.float64
+        return OnlineFilter(self._filter, self._n_chans if n_chans is None else n_chans, dtype=dtype,
+                            out_dtype=out_dtype, device=device)
 
     def _plan_for(self, device):
         """Filter plan on ``device`` (default: the current one).  The plan's tables live in that
@@ -773,9 +829,14 @@ def find_period_batched(parrms, search_samples=None, assumed_periods=None, outli
         active = list(range(len(parrms)))
         while active:
             answers = {}
-            steps = [i for i in active if not pending[i].is_grid]
+            # what goes into the shared call: optimiser steps, and stage grids small enough to be
+            # latency-bound themselves (few channels, a few hundred candidates) -- unless the object
+            # evaluates its grids its own way (ShardedPARRM's candidate slices)
+            steps = [i for i in active
+                     if not pending[i].is_grid
+                     or (pending[i].periods.size <= _SMALL_GRID and type(parrms[i])._grid_errors is PARRM._grid_errors)]
             for i in active:
-                if pending[i].is_grid:
+                if i not in steps:
                     answers[i] = parrms[i]._answer(pending[i], grid_ws)
             if steps:
                 for i, errors in zip(steps, _hip.fit_errors_multi([(pending[i], spaces[i]) for i in steps])):

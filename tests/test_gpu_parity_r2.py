@@ -431,3 +431,76 @@ def test_find_period_batched_amortises_the_optimiser_steps():
     assert a == b
     print(f"\n8 sites: sequential {1e3 * (t1 - t0):.1f} ms, batched {1e3 * (t2 - t1):.1f} ms")
     assert t2 - t1 < 0.8 * (t1 - t0)
+
+
+# ---------------------------------------------------------------------------- ingestion + online mode (f4)
+@pytest.mark.parametrize("direction", ["both", "past", "future"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_online_filter_equals_filter_data_on_the_concatenation(direction, dtype):
+    """Blocks of irregular length pushed through ``PARRM.online()``: the concatenation of what comes
+    back equals the oracle's ``filter_data`` of the whole signal, recording edges included; the
+    one-sided filter that reaches only earlier samples ("future", parrm.py:819-820) has zero latency."""
+    from pyparrm_amd.streaming import OnlineFilter
+
+    n = 61000
+    x = synth_recording(3, n, 22000, 130, seed=21).astype(dtype)
+    p = PARRM(x, 22000, 130, verbose=False)
+    p._period = np.float64(169.2359)
+    p.create_filter(filter_direction=direction, omit_n_samples=2)
+    ref = orc.filter_data_direct(x, p.filter)
+    stream = p.online()
+    assert isinstance(stream, OnlineFilter)
+    hw = p.settings["filter"]["filter_half_width"]
+    assert 0 <= stream.latency <= hw
+    rng = np.random.default_rng(3)
+    got, pos = [], 0
+    while pos < n:
+        k = int(rng.choice([1, 7, 500, 2372, 9000, 20000]))
+        block = x[:, pos:pos + k]
+        out = stream.push(block)
+        pos += block.shape[1]
+        assert out.shape[0] == 3 and stream.n_emitted == max(pos - stream.latency, 0)
+        got.append(out)
+    got.append(stream.finish())
+    y = np.concatenate(got, axis=1)
+    assert y.shape == ref.shape and y.dtype == np.float64
+    tol = 1e-10 if dtype == np.float64 else 1e-6
+    assert np.abs(y - ref).max() <= tol * np.abs(ref).max()
+    if direction == "future":
+        assert stream.latency == 0
+    with pytest.raises(ValueError, match="finished"):
+        stream.push(x[:, :5])
+
+
+def test_filter_file_npy_roundtrip_and_memmap_find_period(tmp_path):
+    """.npy on disk -> memory map -> pinned chunks -> device -> .npy (data/example_data.py:13-30 ships the
+    reference's recordings as .npy files).  The memory-mapped recording also goes through the whole
+    facade: find_period streams its statistics pass and gathers the stage columns on the host."""
+    from pyparrm_amd.streaming import filter_file
+
+    x = synth_recording_exact(5, 400_000, 22000.0 / 130.0 * (1 + 2e-4), seed=88)
+    src = tmp_path / "recording.npy"
+    np.save(src, x)
+    resident = PARRM(x, 22000.0, 130.0, verbose=False)
+    resident.find_period(random_seed=6)
+    mapped = np.load(src, mmap_mode="r")
+    p = PARRM(mapped, 22000.0, 130.0, verbose=False)
+    p.find_period(random_seed=6)
+    assert abs(p.period - resident.period) <= 1e-9 * resident.period
+    p.create_filter()
+    ref = orc.filter_data_direct(x, p.filter)
+    y = p.filter_data()
+    assert np.abs(y - ref).max() <= 1e-10 * np.abs(ref).max()
+    for chunk in (0, 30011, 150000):
+        dst = tmp_path / f"filtered_{chunk}.npy"
+        out = filter_file(p.filter, src, dst, chunk_samples=chunk)
+        assert out.shape == x.shape
+        back = np.load(dst)
+        assert np.abs(back - ref).max() <= 1e-10 * np.abs(ref).max()
+    # float32 file -> float32 file
+    np.save(tmp_path / "rec32.npy", x.astype(np.float32))
+    out32 = filter_file(p.filter, tmp_path / "rec32.npy", tmp_path / "out32.npy", chunk_samples=70000,
+                        out_dtype=np.float32)
+    assert out32.dtype == np.float32
+    ref32 = orc.filter_data_direct(x.astype(np.float32), p.filter)
+    assert np.abs(np.load(tmp_path / "out32.npy") - ref32).max() <= 1e-5 * np.abs(ref32).max()
