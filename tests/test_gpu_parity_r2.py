@@ -504,3 +504,31 @@ def test_filter_file_npy_roundtrip_and_memmap_find_period(tmp_path):
     assert out32.dtype == np.float32
     ref32 = orc.filter_data_direct(x.astype(np.float32), p.filter)
     assert np.abs(np.load(tmp_path / "out32.npy") - ref32).max() <= 1e-5 * np.abs(ref32).max()
+
+
+# ---------------------------------------------------------------------------- PSD helper (f3)
+@pytest.mark.parametrize("n_chans,n_times,n_points", [(1, 100, 10), (2, 100, 10), (3, 5000, 4400), (2, 3000, 4401),
+                                                      (4, 60000, 44000)])
+def test_compute_psd_matches_scipy_formulation(n_chans, n_times, n_points):
+    """_utils/_power.py:55-68 restated with scipy.fft (the reference's own transform), including its
+    truncate-or-pad ``fft(x, n)`` and its ``psd[:-1] *= 2`` on the channel axis; rtol 1e-5 (float32)."""
+    from scipy.fft import fft, fftfreq
+
+    from pyparrm_amd._utils._power import compute_psd
+
+    fs = 22000
+    data = np.random.default_rng(44).standard_normal((n_chans, n_times)) * 3.0
+    for max_freq in (None, fs / 4.0):
+        ref_f = np.abs(fftfreq(n_points, 1.0 / fs)[1:(n_points // 2) + 1])
+        mf = ref_f[-1] if max_freq is None else max_freq
+        cut = np.argwhere(ref_f <= mf)[-1][0]
+        co = fft(data.astype(np.float32), n_points)[..., 1:(n_points // 2) + 1]
+        ref = (1.0 / (fs * n_points)) * np.abs(co).astype(np.float32) ** 2
+        ref[:-1] *= 2
+        ref_f, ref = ref_f[: cut + 1], ref[..., : cut + 1]
+        freqs, psd = compute_psd(data, fs, n_points, max_freq=max_freq, n_jobs=2)
+        assert isinstance(freqs, np.ndarray) and isinstance(psd, np.ndarray) and psd.dtype == np.float32
+        assert psd.shape == ref.shape and np.array_equal(freqs, ref_f)
+        np.testing.assert_allclose(psd, ref, rtol=1e-5, atol=1e-5 * float(ref.max()))
+    d_psd = compute_psd(torch.from_numpy(data).cuda(), fs, n_points)[1]
+    assert d_psd.is_cuda and d_psd.shape[0] == n_chans
