@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--samples", type=int, default=10_000_000)
     ap.add_argument("--mode", choices=["strong", "weak"], default="strong",
                     help="N > 1: one recording channel-sharded (strong) or one recording per rank (weak)")
+    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="cfg3 (default): the headline, resident f64 find_period + filter_data; cfg5: BASELINE "
+                         "configs[4], float32 recording streamed from page-locked host memory, filter_data only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-only", action="store_true", help="time filter_data alone (config 2 style)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -98,6 +101,90 @@ def run_cpu_baseline():
     return {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "period", "configs", "wall_s")}
 
 
+def run_cfg5(args, rank, local_rank, world):
+    """BASELINE configs[4]: 1024 ch x 50 Msample float32, filter_data only, streamed in host-pinned
+    chunks; channel blocks per GPU (one process each), no exchange.  The link, not the kernel, is the
+    bound: reports GB/s over PCIe per GPU next to the metric.  ``--chans/--samples`` size the WHOLE
+    recording (defaults here: 1024 x 50 M; one GPU of an 8-GPU run holds 128 channels)."""
+    import torch
+
+    from pyparrm_amd import PARRM, _hip
+    from pyparrm_amd.sharding import channel_shard, timed_steps
+
+    _hip.require_gpu()
+    if args.single_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    n_chans = args.chans if args.chans != 256 else 1024
+    n_samples = args.samples if args.samples != 10_000_000 else 50_000_000
+    lo, hi = channel_shard(n_chans, rank, world)
+    rows = hi - lo
+    # this rank's block, generated on the device in pieces and parked in page-locked host memory
+    x = torch.empty((rows, n_samples), dtype=torch.float32).pin_memory()
+    y = torch.empty((rows, n_samples), dtype=torch.float32).pin_memory()
+    gen = torch.Generator(device="cuda")
+    period = FS / F_ART * (1 + 3e-5)
+    for c in range(rows):
+        gen.manual_seed(5000 + lo + c)
+        n = torch.arange(n_samples, dtype=torch.float64, device="cuda")
+        u = torch.remainder((n + 3.0 * (lo + c)) / period, 1.0)
+        art = torch.clamp(1.0 - torch.abs(u - 0.25) * 20.0, min=0.0) - 0.5 * torch.clamp(1.0 - torch.abs(u - 0.35) * 12.0, min=0.0)
+        row = torch.randn(n_samples, dtype=torch.float32, device="cuda", generator=gen) + (5.0 * art).to(torch.float32)
+        x[c].copy_(row)
+        del n, u, art, row
+    torch.cuda.synchronize()
+    p = PARRM(np.zeros((1, n_samples)), FS, F_ART, verbose=False)
+    p._period = np.float64(period)
+    p.create_filter()
+    plan = _hip.FilterPlan(p.filter, device=local_rank)
+    x_np, y_np = x.numpy(), y.numpy()
+
+    def step():
+        plan.apply_host(x_np, out_dtype=np.float32, out=y_np)  # synchronous: returns when y is complete
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(step, args.steps, 0, dist=dist, sync=torch.cuda.synchronize)
+    if rank == 0:
+        info = plan.info
+        per_gpu_bytes = 2.0 * rows * n_samples * 4
+        out = {
+            "metric": "Msamples/s through filter_data (host-streamed, configs[4])",
+            "value": n_chans * n_samples * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"{n_chans} ch x {n_samples} samples float32 in page-locked host memory, channel blocks of "
+                             f"{rows} rows per GPU, filter_data only (f32 out), streamed in time chunks with a "
+                             f"{int(info.half_width)}-sample halo over two streams"),
+                "parallelism": f"{world} GPU(s), channel blocks, no exchange",
+            },
+            "roofline": {"bound": "pcie", "achieved": per_gpu_bytes * args.steps / elapsed / 1e9, "peak": 2 * 63.0,
+                         "unit": "GB/s", "frac": per_gpu_bytes * args.steps / elapsed / 1e9 / (2 * 63.0), "traffic": None,
+                         "note": "per GPU, host->device + device->host together; PCIe Gen5 x16 is 63 GB/s each way"},
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +194,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if args.workload == "cfg5":
+        return run_cfg5(args, rank, local_rank, world)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

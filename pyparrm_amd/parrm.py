@@ -356,7 +356,7 @@ class PARRM:
         total = None
         for lo in range(0, self._n_samples - 1, step):
             hi = min(lo + step, self._n_samples - 1)  # differences lo .. hi-1 need samples lo .. hi
-            host = np.ascontiguousarray(data[:, lo:hi + 1])
+            host = np.array(data[:, lo:hi + 1])  # a fresh, writable block (the source may be a read-only map)
             if host.dtype not in (np.float32, np.float64):
                 host = host.astype(np.float64)
             part = _hip.absdiff_mean(torch.from_numpy(host).cuda()) * float(hi - lo)

@@ -532,3 +532,31 @@ def test_compute_psd_matches_scipy_formulation(n_chans, n_times, n_points):
         np.testing.assert_allclose(psd, ref, rtol=1e-5, atol=1e-5 * float(ref.max()))
     d_psd = compute_psd(torch.from_numpy(data).cuda(), fs, n_points)[1]
     assert d_psd.is_cuda and d_psd.shape[0] == n_chans
+
+
+# ---------------------------------------------------------------------------- config 5 at 1-GPU scale
+def test_config5_streaming_channel_blocks_vs_oracle():
+    """BASELINE configs[4] in miniature: a float32 recording in host memory, two channel blocks (what
+    two ranks would hold) each streamed through ``parrm_filter_host`` in time chunks with pre-locked
+    buffers, float32 and float64 outputs, against the ORACLE on the whole recording."""
+    from pyparrm_amd import sharding as sh
+
+    x = synth_recording_exact(6, 700_000, 22000.0 / 130.0 * (1 + 3e-5), seed=55, dtype=np.float32)
+    filt = orc.generate_filter(169.2359, orc.default_filter_half_width(x.shape[1], 169.2359, 0, 169.2359 / 50))
+    ref = orc.filter_data_direct(x, filt)
+    plan = _hip.FilterPlan(filt)
+    for out_dtype, tol in ((np.float32, 2e-6), (np.float64, 1e-10)):
+        blocks = []
+        for rank in range(2):
+            mine = np.ascontiguousarray(sh.shard_recording(x, rank, 2))
+            out = np.empty(mine.shape, dtype=out_dtype)
+            _hip.pin_host(mine)
+            _hip.pin_host(out)
+            try:
+                plan.apply_host(mine, out_dtype=out_dtype, chunk_samples=90_001, out=out)
+            finally:
+                _hip.unpin_host(mine)
+                _hip.unpin_host(out)
+            blocks.append(out)
+        y = np.concatenate(blocks)
+        assert y.dtype == out_dtype and np.abs(y - ref).max() <= tol * np.abs(ref).max()
