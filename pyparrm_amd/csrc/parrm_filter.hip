@@ -38,18 +38,8 @@ __global__ void __launch_bounds__(256) filter_gather_kernel(FilterArgs a) {
     if (i >= a.out_len) return;
     const int64_t n = a.out_first + i;
     const TI *x = static_cast<const TI *>(a.x);
-    for (int64_t c = blockIdx.y; c < a.n_chans; c += gridDim.y) {
-        const TI *row = x + c * a.ldx - a.buf_first;
-        double s = 0.0;
-        for (int r = 0; r < a.n_runs; ++r) {
-            int64_t lo = n - a.runs[2 * r + 1];
-            int64_t hi = n - a.runs[2 * r];
-            if (lo < 0) lo = 0;
-            if (hi > a.n_total - 1) hi = a.n_total - 1;
-            for (int64_t g = lo; g <= hi; ++g) s += static_cast<double>(row[g]);
-        }
-        emit<TO>(a, c, n, static_cast<double>(row[n]), s);
-    }
+    (void)x;
+    for (int64_t c = blockIdx.y; c < a.n_chans; c += gridDim.y) gather_output<TI, TO>(a, c, n);
 }
 
 // One workgroup = one (channel, stretch).  Threads r < q own residue r of the stretch; rows of q
@@ -102,6 +92,7 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
     }
 
     const bool active = tid < q;
+    bool bad = false;  // this thread produced a non-finite result (mark_poison at the end)
     double S = 0.0;
     if (active) {  // full evaluation once per stretch: S(s0 + tid)
         double s_a = 0.0, s_b = 0.0;
@@ -131,7 +122,7 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
             for (int j = 0; j < G; ++j) {
                 const int rel = (m + j) * q + tid;
                 if ((m + j) * q >= len) break;
-                if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
+                if (rel < len) bad |= emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
                 const int relb = rel * kEl;
                 double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
@@ -159,6 +150,7 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
             __syncthreads();
         }
     }
+    mark_poison(a, bad, c, s0, s1);
 }
 
 }  // namespace
@@ -262,7 +254,32 @@ int resolve_kernel(const parrm_filter_plan *p, int64_t n_chans, int64_t out_len)
 }
 
 template <typename TI, typename TO>
+int launch_main(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream);
+
+// Recurrence kernels run with the poison flags (parrm_filter_internal.h): flags from the stream-ordered
+// allocator, cleared, main kernel, repair pass over the marked tiles, flags back to the pool.
+template <typename TI, typename TO>
 int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
+    if (kernel == PARRM_KERNEL_GATHER) return launch_main<TI, TO>(p, a, kernel, stream);
+    a.poison_tiles = (a.out_len + kPoisonTile - 1) / kPoisonTile;
+    const int64_t n_tiles = a.n_chans * a.poison_tiles;
+    void *flags = nullptr;
+    PARRM_HIP_CHECK(hipMallocAsync(&flags, static_cast<size_t>(n_tiles) * sizeof(unsigned int), stream));
+    a.poison = static_cast<unsigned int *>(flags);
+    hipError_t e = hipMemsetAsync(flags, 0, static_cast<size_t>(n_tiles) * sizeof(unsigned int), stream);
+    int rc = e == hipSuccess ? launch_main<TI, TO>(p, a, kernel, stream) : parrm::hip_fail(e, "filter: clearing the poison flags");
+    if (rc == PARRM_OK) {
+        const int64_t blocks = (n_tiles + kRepairTilesPerBlock - 1) / kRepairTilesPerBlock;
+        hipLaunchKernelGGL((filter_repair_kernel<TI, TO>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = parrm::hip_fail(e, "filter: repair launch");
+    }
+    (void)hipFreeAsync(flags, stream);
+    return rc;
+}
+
+template <typename TI, typename TO>
+int launch_main(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
     if (kernel == PARRM_KERNEL_PHASE) return launch_phase<TI, TO>(p, a, stream);
     if (kernel == PARRM_KERNEL_GATHER) {
         const int block = 256;

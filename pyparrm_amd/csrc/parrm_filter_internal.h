@@ -24,7 +24,18 @@ struct FilterArgs {
     int32_t q, ring_mask, rows_per_fill;
     int64_t stretch_len, n_stretch;
     double inv_taps;
+    // Non-finite inputs.  The recurrence kernels carry a running sum per residue class; a NaN/Inf sample
+    // that enters it never leaves (NaN - NaN), so a workgroup that ever produces a non-finite result
+    // marks the 64 K-output tiles of its stretch here and filter_repair_kernel recomputes those tiles
+    // tap by tap: outputs whose taps reach a non-finite sample are 0 (parrm.py:869), every other output
+    // is exact -- the same answer from every kernel variant and every chunking.  NULL = not tracked
+    // (the gather kernel, which is exact by construction).
+    unsigned int *poison;      // [n_chans][poison_tiles]
+    int64_t poison_tiles;      // tiles per channel
 };
+
+constexpr int64_t kPoisonTile = 65536;
+constexpr int kRepairTilesPerBlock = 16;
 
 // number of taps whose source sample n-w lies inside [0, n_total)
 __device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
@@ -36,8 +47,9 @@ __device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
     return a.tapcum[w_hi + hw + 1] - a.tapcum[w_lo + hw];
 }
 
+// returns true when the result was not finite (and 0 was stored, parrm.py:869)
 template <typename TO>
-__device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
+__device__ inline bool emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
     double y;
     if (n >= a.hw && n + a.hw < a.n_total) {
         y = xc - s * a.inv_taps;
@@ -45,8 +57,48 @@ __device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc
         const int v = valid_taps(a, n);
         y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
     }
-    if (!isfinite(y)) y = 0.0;  // parrm.py:869
+    const bool bad = !isfinite(y);
+    if (bad) y = 0.0;  // parrm.py:869
     static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);
+    return bad;
+}
+
+// end of a recurrence workgroup: mark the tiles of outputs [s0, s1) of channel c when any thread saw a
+// non-finite result (every thread of the workgroup calls this)
+__device__ inline void mark_poison(const FilterArgs &a, bool bad, int64_t c, int64_t s0, int64_t s1) {
+    if (a.poison == nullptr) return;
+    if (!__syncthreads_or(bad ? 1 : 0)) return;
+    const int64_t t0 = (s0 - a.out_first) / kPoisonTile, t1 = (s1 - 1 - a.out_first) / kPoisonTile;
+    for (int64_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) a.poison[c * a.poison_tiles + t] = 1u;
+}
+
+// direct evaluation of one output from global memory (the gather kernel's arithmetic)
+template <typename TI, typename TO>
+__device__ inline bool gather_output(const FilterArgs &a, int64_t c, int64_t n) {
+    const TI *row = static_cast<const TI *>(a.x) + c * a.ldx - a.buf_first;
+    double s = 0.0;
+    for (int r = 0; r < a.n_runs; ++r) {
+        int64_t lo = n - a.runs[2 * r + 1];
+        int64_t hi = n - a.runs[2 * r];
+        if (lo < 0) lo = 0;
+        if (hi > a.n_total - 1) hi = a.n_total - 1;
+        for (int64_t g = lo; g <= hi; ++g) s += static_cast<double>(row[g]);
+    }
+    return emit<TO>(a, c, n, static_cast<double>(row[n]), s);
+}
+
+// One workgroup looks at kRepairTilesPerBlock tile flags and recomputes the marked tiles.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) filter_repair_kernel(FilterArgs a) {
+    const int64_t n_tiles = a.n_chans * a.poison_tiles;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kRepairTilesPerBlock;
+    for (int64_t t = first; t < first + kRepairTilesPerBlock && t < n_tiles; ++t) {
+        if (a.poison[t] == 0u) continue;  // workgroup-uniform
+        const int64_t c = t / a.poison_tiles, tile = t - c * a.poison_tiles;
+        const int64_t lo = tile * kPoisonTile;
+        const int64_t hi = lo + kPoisonTile < a.out_len ? lo + kPoisonTile : a.out_len;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
+    }
 }
 
 template <typename TI>

@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         }
     }
 
+    bool bad = false;  // this thread produced a non-finite result (mark_poison at the end)
     // S at row 0 for this residue: full evaluation, once per stretch (every group, redundantly)
     double S = 0.0;
     if (active) {
@@ -465,7 +466,9 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-                        if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+                        const bool nf = !isfinite(yv);
+                        bad |= nf;
+                        if (nf) yv = 0.0;  // parrm.py:869
                         (yout + static_cast<int64_t>(i) * q)[static_cast<unsigned>(r)] = static_cast<TO>(yv);
                         s_row += delta[i];
                     }
@@ -474,7 +477,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int rel = (m + i) * q + r;
-                    if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
+                    if (rel < len) bad |= emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
                     s_row += delta[i];
                 }
             }
@@ -548,7 +551,9 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-            if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+            const bool nf = !isfinite(yv);
+            bad |= nf;
+            if (nf) yv = 0.0;  // parrm.py:869
             const TO yo = static_cast<TO>(yv);
             if constexpr (sizeof(TO) == 8) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
@@ -580,6 +585,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             mk += 2 * NGR;
         }
     }
+    mark_poison(a, bad, c, s0, s1);
 }
 
 int pad_half(int64_t n) {

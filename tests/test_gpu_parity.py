@@ -247,6 +247,40 @@ def test_filter_nonfinite_outputs_are_zeroed():
         np.testing.assert_allclose(y[1], orc.filter_data_direct(x[1:], filt)[0], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("period,hw,direction", [(169.23584615384616, 2372, "both"), (7.742402205597892, 2477, "both"),
+                                                 (169.23584615384616, 2372, "future")])
+def test_filter_nonfinite_samples_only_zero_the_outputs_they_reach(period, hw, direction):
+    """the recurrence kernels carry running sums, so a NaN/Inf sample used to wipe every later
+    output of its residue class up to the end of the stretch.  Now every kernel variant, the window form,
+    the host-streamed form and the online form give the oracle's answer: 0 exactly where a tap reaches a
+    non-finite sample (parrm.py:869), the exact value everywhere else -- on the poisoned channel too."""
+    filt = orc.generate_filter(period, hw, 0, direction, None)
+    n = 400_000
+    x = synth_recording(3, n, 22000, 130, seed=12)
+    x[0, 123_456] = np.nan
+    x[0, 300_000:300_003] = np.inf
+    x[2, 5] = -np.inf
+    x[2, n - 2] = np.nan
+    ref = orc.filter_data_direct(x, filt)
+    assert np.count_nonzero(ref[0] == 0) < 4 * (2 * hw + 1) + 8  # only the reach of the bad samples is zeroed
+    plan = _hip.FilterPlan(filt)
+    for k in _variants(plan):
+        y = _run_filter(plan, x, k)
+        assert np.all(np.isfinite(y))
+        _assert_filter_close(y, ref)
+        assert np.array_equal(y == 0, ref == 0), k
+    streamed = plan.apply_host(x, chunk_samples=90_001)
+    _assert_filter_close(streamed, ref)
+    assert np.array_equal(streamed == 0, ref == 0)
+    from pyparrm_amd.streaming import OnlineFilter
+
+    stream = OnlineFilter(filt, 3)
+    parts = [stream.push(x[:, lo:lo + 70_000]) for lo in range(0, n, 70_000)] + [stream.finish()]
+    online = np.concatenate(parts, axis=1)
+    _assert_filter_close(online, ref)
+    assert np.array_equal(online == 0, ref == 0)
+
+
 # ---------------------------------------------------------------------------- find_period pieces
 def test_absdiff_mean_and_gather(golden):
     g = golden("standardise.npz")
