@@ -92,7 +92,6 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
     }
 
     const bool active = tid < q;
-    bool bad = false;  // this thread produced a non-finite result (mark_poison at the end)
     double S = 0.0;
     if (active) {  // full evaluation once per stretch: S(s0 + tid)
         double s_a = 0.0, s_b = 0.0;
@@ -122,7 +121,7 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
             for (int j = 0; j < G; ++j) {
                 const int rel = (m + j) * q + tid;
                 if ((m + j) * q >= len) break;
-                if (rel < len) bad |= emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
+                if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
                 const int relb = rel * kEl;
                 double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
@@ -150,7 +149,6 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
             __syncthreads();
         }
     }
-    mark_poison(a, bad, c, s0, s1);
 }
 
 }  // namespace
@@ -254,33 +252,23 @@ int resolve_kernel(const parrm_filter_plan *p, int64_t n_chans, int64_t out_len)
 }
 
 template <typename TI, typename TO>
-int launch_main(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream);
+int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStream_t stream);
 
-// Recurrence kernels run with the poison flags (parrm_filter_internal.h): flags from the stream-ordered
-// allocator, cleared, main kernel, repair pass over the marked tiles, flags back to the pool.
+// A recurrence launch is followed by the repair pass (parrm_filter_internal.h: non-finite inputs).
 template <typename TI, typename TO>
 int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
-    if (kernel == PARRM_KERNEL_GATHER) return launch_main<TI, TO>(p, a, kernel, stream);
-    a.poison_tiles = (a.out_len + kPoisonTile - 1) / kPoisonTile;
-    const int64_t n_tiles = a.n_chans * a.poison_tiles;
-    void *flags = nullptr;
-    PARRM_HIP_CHECK(hipMallocAsync(&flags, static_cast<size_t>(n_tiles) * sizeof(unsigned int), stream));
-    a.poison = static_cast<unsigned int *>(flags);
-    hipError_t e = hipMemsetAsync(flags, 0, static_cast<size_t>(n_tiles) * sizeof(unsigned int), stream);
-    int rc = e == hipSuccess ? launch_main<TI, TO>(p, a, kernel, stream) : parrm::hip_fail(e, "filter: clearing the poison flags");
-    if (rc == PARRM_OK) {
-        const int64_t blocks = (n_tiles + kRepairTilesPerBlock - 1) / kRepairTilesPerBlock;
-        hipLaunchKernelGGL((filter_repair_kernel<TI, TO>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) rc = parrm::hip_fail(e, "filter: repair launch");
-    }
-    (void)hipFreeAsync(flags, stream);
-    return rc;
+    const int rc = launch_main<TI, TO>(p, &a, kernel, stream);
+    if (rc != PARRM_OK || kernel == PARRM_KERNEL_GATHER || getenv("PARRM_NO_REPAIR_PASS")) return rc;
+    const int64_t blocks = (a.n_chans * a.n_stretch + kRepairStretchesPerBlock - 1) / kRepairStretchesPerBlock;
+    hipLaunchKernelGGL((filter_repair_kernel<TI, TO>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, a);
+    PARRM_HIP_CHECK(hipGetLastError());
+    return PARRM_OK;
 }
 
 template <typename TI, typename TO>
-int launch_main(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
-    if (kernel == PARRM_KERNEL_PHASE) return launch_phase<TI, TO>(p, a, stream);
+int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStream_t stream) {
+    FilterArgs &a = *args;
+    if (kernel == PARRM_KERNEL_PHASE) return launch_phase<TI, TO>(p, args, stream);
     if (kernel == PARRM_KERNEL_GATHER) {
         const int block = 256;
         const int64_t gx = (a.out_len + block - 1) / block;

@@ -24,18 +24,7 @@ struct FilterArgs {
     int32_t q, ring_mask, rows_per_fill;
     int64_t stretch_len, n_stretch;
     double inv_taps;
-    // Non-finite inputs.  The recurrence kernels carry a running sum per residue class; a NaN/Inf sample
-    // that enters it never leaves (NaN - NaN), so a workgroup that ever produces a non-finite result
-    // marks the 64 K-output tiles of its stretch here and filter_repair_kernel recomputes those tiles
-    // tap by tap: outputs whose taps reach a non-finite sample are 0 (parrm.py:869), every other output
-    // is exact -- the same answer from every kernel variant and every chunking.  NULL = not tracked
-    // (the gather kernel, which is exact by construction).
-    unsigned int *poison;      // [n_chans][poison_tiles]
-    int64_t poison_tiles;      // tiles per channel
 };
-
-constexpr int64_t kPoisonTile = 65536;
-constexpr int kRepairTilesPerBlock = 16;
 
 // number of taps whose source sample n-w lies inside [0, n_total)
 __device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
@@ -47,9 +36,8 @@ __device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
     return a.tapcum[w_hi + hw + 1] - a.tapcum[w_lo + hw];
 }
 
-// returns true when the result was not finite (and 0 was stored, parrm.py:869)
 template <typename TO>
-__device__ inline bool emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
+__device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
     double y;
     if (n >= a.hw && n + a.hw < a.n_total) {
         y = xc - s * a.inv_taps;
@@ -57,24 +45,13 @@ __device__ inline bool emit(const FilterArgs &a, int64_t c, int64_t n, double xc
         const int v = valid_taps(a, n);
         y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
     }
-    const bool bad = !isfinite(y);
-    if (bad) y = 0.0;  // parrm.py:869
+    if (!isfinite(y)) y = 0.0;  // parrm.py:869
     static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);
-    return bad;
-}
-
-// end of a recurrence workgroup: mark the tiles of outputs [s0, s1) of channel c when any thread saw a
-// non-finite result (every thread of the workgroup calls this)
-__device__ inline void mark_poison(const FilterArgs &a, bool bad, int64_t c, int64_t s0, int64_t s1) {
-    if (a.poison == nullptr) return;
-    if (!__syncthreads_or(bad ? 1 : 0)) return;
-    const int64_t t0 = (s0 - a.out_first) / kPoisonTile, t1 = (s1 - 1 - a.out_first) / kPoisonTile;
-    for (int64_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) a.poison[c * a.poison_tiles + t] = 1u;
 }
 
 // direct evaluation of one output from global memory (the gather kernel's arithmetic)
 template <typename TI, typename TO>
-__device__ inline bool gather_output(const FilterArgs &a, int64_t c, int64_t n) {
+__device__ inline void gather_output(const FilterArgs &a, int64_t c, int64_t n) {
     const TI *row = static_cast<const TI *>(a.x) + c * a.ldx - a.buf_first;
     double s = 0.0;
     for (int r = 0; r < a.n_runs; ++r) {
@@ -84,20 +61,39 @@ __device__ inline bool gather_output(const FilterArgs &a, int64_t c, int64_t n) 
         if (hi > a.n_total - 1) hi = a.n_total - 1;
         for (int64_t g = lo; g <= hi; ++g) s += static_cast<double>(row[g]);
     }
-    return emit<TO>(a, c, n, static_cast<double>(row[n]), s);
+    emit<TO>(a, c, n, static_cast<double>(row[n]), s);
 }
 
-// One workgroup looks at kRepairTilesPerBlock tile flags and recomputes the marked tiles.
+// Non-finite inputs and the recurrence kernels.  Those kernels carry a running tap sum per residue
+// class of a (channel, stretch); a NaN/Inf sample that enters it never leaves (NaN - NaN, Inf - Inf),
+// so from there to the end of the stretch every output of that class is non-finite and is stored as
+// 0 (parrm.py:869) -- although only the outputs whose taps reach the bad sample should be.  Because
+// the poison survives to the end of the stretch, a poisoned stretch always shows an exact 0 among its
+// last q <= 512 outputs (each residue class has one there).  This pass runs behind every recurrence
+// launch: it probes those outputs of every stretch (0.1 % of the output, L2-warm) and recomputes the
+// stretches that show a 0 where a tap is in range, tap by tap as the gather kernel does.  Clean
+// recordings pay the probe only (an exact 0 by coincidence costs one needless, correct recompute), and
+// the hot kernels carry nothing for it -- a flag kept in the phase kernel cost it a VGPR, which is one
+// wave per SIMD at its 80-register budget.  Result: every kernel variant and every chunking returns
+// what the direct evaluation returns, on the poisoned channel too.
+constexpr int kRepairStretchesPerBlock = 4;
+constexpr int kRepairProbe = 512;
+
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) filter_repair_kernel(FilterArgs a) {
-    const int64_t n_tiles = a.n_chans * a.poison_tiles;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kRepairTilesPerBlock;
-    for (int64_t t = first; t < first + kRepairTilesPerBlock && t < n_tiles; ++t) {
-        if (a.poison[t] == 0u) continue;  // workgroup-uniform
-        const int64_t c = t / a.poison_tiles, tile = t - c * a.poison_tiles;
-        const int64_t lo = tile * kPoisonTile;
-        const int64_t hi = lo + kPoisonTile < a.out_len ? lo + kPoisonTile : a.out_len;
-        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
+    const int64_t n_str = a.n_chans * a.n_stretch;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kRepairStretchesPerBlock;
+    const TO *y = static_cast<const TO *>(a.y);
+    for (int64_t s = first; s < first + kRepairStretchesPerBlock && s < n_str; ++s) {
+        const int64_t c = s / a.n_stretch, st = s - c * a.n_stretch;
+        const int64_t o0 = st * a.stretch_len;
+        const int64_t o1 = o0 + a.stretch_len < a.out_len ? o0 + a.stretch_len : a.out_len;
+        const int64_t p0 = o1 - kRepairProbe > o0 ? o1 - kRepairProbe : o0;
+        int hit = 0;
+        for (int64_t i = p0 + threadIdx.x; i < o1; i += blockDim.x)
+            if (y[c * a.ldy + i] == TO(0) && valid_taps(a, a.out_first + i) > 0) hit = 1;
+        if (!__syncthreads_or(hit)) continue;  // workgroup-uniform
+        for (int64_t i = o0 + threadIdx.x; i < o1; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
     }
 }
 
@@ -145,6 +141,7 @@ struct parrm_filter_plan {
 namespace parrm_filter {
 // parrm_filter_phase.hip
 void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *plan, std::vector<int32_t> *table);
+// (fills a->stretch_len / a->n_stretch: the repair pass needs the stretch geometry of the launch)
 template <typename TI, typename TO>
-int launch_phase(const parrm_filter_plan *plan, FilterArgs a, hipStream_t stream);
+int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream);
 }  // namespace parrm_filter

@@ -234,7 +234,6 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         }
     }
 
-    bool bad = false;  // this thread produced a non-finite result (mark_poison at the end)
     // S at row 0 for this residue: full evaluation, once per stretch (every group, redundantly)
     double S = 0.0;
     if (active) {
@@ -466,9 +465,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-                        const bool nf = !isfinite(yv);
-                        bad |= nf;
-                        if (nf) yv = 0.0;  // parrm.py:869
+                        if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
                         (yout + static_cast<int64_t>(i) * q)[static_cast<unsigned>(r)] = static_cast<TO>(yv);
                         s_row += delta[i];
                     }
@@ -477,7 +474,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int rel = (m + i) * q + r;
-                    if (rel < len) bad |= emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
+                    if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
                     s_row += delta[i];
                 }
             }
@@ -551,9 +548,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-            const bool nf = !isfinite(yv);
-            bad |= nf;
-            if (nf) yv = 0.0;  // parrm.py:869
+            if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
             const TO yo = static_cast<TO>(yv);
             if constexpr (sizeof(TO) == 8) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
@@ -585,7 +580,6 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             mk += 2 * NGR;
         }
     }
-    mark_poison(a, bad, c, s0, s1);
 }
 
 int pad_half(int64_t n) {
@@ -793,7 +787,8 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
 #endif  // PARRM_PHASE_WITH_PLAN
 
 template <typename TI, typename TO, int DP>
-static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs a, PhaseGeom g, hipStream_t stream) {
+static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, PhaseGeom g, hipStream_t stream) {
+    FilterArgs &a = *args;
     void (*kern)(FilterArgs, PhaseGeom) = nullptr;
     switch (g.rows * 2 + (g.wrap ? 1 : 0)) {
         case 4: kern = filter_phase_kernel<TI, TO, DP, 2, false>; break;
@@ -852,7 +847,7 @@ static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs a, PhaseGeom
 }
 
 template <typename TI, typename TO>
-int launch_phase(const parrm_filter_plan *plan, FilterArgs a, hipStream_t stream) {
+int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream) {
     PhaseGeom g = plan->phase;
     g.tab = plan->d_phase_tab;
     if (const char *env = getenv("PARRM_DEBUG_FLAGS")) g.debug = atoi(env);  // profiling ablations only
@@ -869,6 +864,6 @@ int launch_phase(const parrm_filter_plan *plan, FilterArgs a, hipStream_t stream
     }
 }
 
-template int launch_phase<PARRM_PHASE_TI, PARRM_PHASE_TO>(const parrm_filter_plan *, FilterArgs, hipStream_t);
+template int launch_phase<PARRM_PHASE_TI, PARRM_PHASE_TO>(const parrm_filter_plan *, FilterArgs *, hipStream_t);
 
 }  // namespace parrm_filter
