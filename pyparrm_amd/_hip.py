@@ -63,6 +63,8 @@ class PlanInfo(C.Structure):
         ("phase_groups", C.c_int32),
         ("phase_rows", C.c_int32),
         ("phase_row_slots", C.c_int32),
+        ("phase_residues", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -70,9 +70,10 @@ __device__ inline void gather_output(const FilterArgs &a, int64_t c, int64_t n) 
 // 0 (parrm.py:869) -- although only the outputs whose taps reach the bad sample should be.  Because
 // the poison survives to the end of the stretch, a poisoned stretch always shows an exact 0 among its
 // last q <= 512 outputs (each residue class has one there).  This pass runs behind every recurrence
-// launch: it probes those outputs of every stretch (0.1 % of the output, L2-warm) and recomputes the
-// stretches that show a 0 where a tap is in range, tap by tap as the gather kernel does.  Clean
-// recordings pay the probe only (an exact 0 by coincidence costs one needless, correct recompute), and
+// launch: it probes those outputs of every stretch (0.1 % of the output, L2-warm); a stretch that shows a
+// 0 where a tap is in range has its input window scanned for non-finite samples (an all-zero channel -- a
+// dead electrode -- shows zeros too), and only a stretch that has one is recomputed, tap by tap as the
+// gather kernel does.  Clean recordings pay the probe only, and
 // the hot kernels carry nothing for it -- a flag kept in the phase kernel cost it a VGPR, which is one
 // wave per SIMD at its 80-register budget.  Result: every kernel variant and every chunking returns
 // what the direct evaluation returns, on the poisoned channel too.
@@ -93,6 +94,17 @@ __global__ void __launch_bounds__(256) filter_repair_kernel(FilterArgs a) {
         for (int64_t i = p0 + threadIdx.x; i < o1; i += blockDim.x)
             if (y[c * a.ldy + i] == TO(0) && valid_taps(a, a.out_first + i) > 0) hit = 1;
         if (!__syncthreads_or(hit)) continue;  // workgroup-uniform
+        // confirm: a non-finite sample within reach of the stretch's outputs (exact zeros alone prove nothing)
+        int64_t g0 = a.out_first + o0 - a.hw, g1 = a.out_first + o1 + a.hw;
+        if (g0 < 0) g0 = 0;
+        if (g0 < a.buf_first) g0 = a.buf_first;
+        if (g1 > a.n_total) g1 = a.n_total;
+        if (g1 > a.buf_first + a.buf_len) g1 = a.buf_first + a.buf_len;
+        const TI *row = static_cast<const TI *>(a.x) + c * a.ldx - a.buf_first;
+        int bad = 0;
+        for (int64_t g = g0 + threadIdx.x; g < g1; g += blockDim.x)
+            if (!isfinite(static_cast<double>(row[g]))) bad = 1;
+        if (!__syncthreads_or(bad)) continue;
         for (int64_t i = o0 + threadIdx.x; i < o1; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
     }
 }
@@ -121,6 +133,30 @@ struct PhaseGeom {
     const int32_t *tab;   // [M][2*d_pad] tap offsets per table row; [3*n_runs] (a', b_lo, b_hi); wrap: [2*d_pad] b
 };
 
+// ---------------------------------------------------------------- phase3 kernel geometry (3 residues per lane)
+constexpr int kP3MaxWide = 8;  // widest unit (columns read: width + 2), and the most wide units per filter
+struct Phase3Geom {
+    int32_t q, guard, n_res;   // stride, mirrored residues per side, columns of the ring (q + 2*guard)
+    int32_t lanes;             // threads per row group (whole waves; 3*lanes >= n_res)
+    int32_t m_slots, rs;       // ring rows; column stride in elements (odd, >= m_slots + 1; template constant)
+    int32_t n_groups;          // NG
+    int32_t a_lo, a_hi;        // tap rows reach from m - a_hi to m - a_lo
+    int32_t n_pairs;           // (+1, -1) single-tap pairs, padded (template constant)
+    int32_t n_wide;            // wide units
+    int32_t wide_w[kP3MaxWide];      // widths 1..kP3MaxWide
+    int32_t wide_sign[kP3MaxWide];   // +1 / -1
+    int32_t n_runs;
+    int32_t row_len;           // table row length: 2*n_pairs + n_wide
+    int32_t debug;             // profiling ablations (PARRM_P3_DEBUG): 1 no single taps, 2 no wide units, 4 no stores, 8 general path only, 16 no loads; results wrong by construction
+    const int32_t *tab;        // [m_slots][row_len] element offsets | [3*n_runs] (a', b_lo, b_hi)
+};
+
+
+// parrm_filter_phase3.hip
+bool plan_phase3(const std::vector<int8_t> &tap, int64_t hw, const PhaseGeom &phase, Phase3Geom *out,
+                 std::vector<int32_t> *table);
+template <typename TI, typename TO>
+int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, hipStream_t stream);
 }  // namespace parrm_filter
 
 struct parrm_filter_plan {
@@ -135,6 +171,9 @@ struct parrm_filter_plan {
     // phase-major kernel (0 groups = not available for this filter)
     parrm_filter::PhaseGeom phase{};
     int32_t *d_phase_tab = nullptr;
+    // three-residues-per-lane form of the phase kernel (n_groups == 0: not available for this filter)
+    parrm_filter::Phase3Geom phase3{};
+    int32_t *d_phase3_tab = nullptr;
 };
 
 
@@ -144,4 +183,9 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
 // (fills a->stretch_len / a->n_stretch: the repair pass needs the stretch geometry of the launch)
 template <typename TI, typename TO>
 int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream);
+// parrm_filter_phase3.hip
+bool plan_phase3(const std::vector<int8_t> &tap, int64_t hw, const PhaseGeom &phase, Phase3Geom *out,
+                 std::vector<int32_t> *table);
+template <typename TI, typename TO>
+int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, hipStream_t stream);
 }  // namespace parrm_filter

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--flags", nargs="*", default=None, help="PARRM_DEBUG_FLAGS values to A/B instead of shapes")
     ap.add_argument("--stretch", nargs="*", default=None, help="PARRM_STRETCH_SAMPLES values to A/B (0 = the plan's own choice)")
+    ap.add_argument("--plan-env", nargs="*", default=None, help="NAME=VALUE settings in force while the plan is BUILT, one arm each")
     ap.add_argument("--env", nargs="*", default=None, help="NAME=VALUE settings to A/B against the default")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--lib", default=None, help="load this build of libparrm_hip.so instead of the in-tree one")
@@ -42,7 +43,15 @@ def main():
     p._period = np.float64(22000.0 / 130.0 * (1 + 3e-5))
     p.create_filter()
     arms = []
-    if args.env:
+    if args.plan_env:
+        for kv in args.plan_env:
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
+            plan = _hip.FilterPlan(p.filter)
+            os.environ.pop(k, None)
+            info = plan.info
+            arms.append((f"plan {kv} (residues/lane {info.phase_residues}, NG={info.phase_groups}, M={info.phase_row_slots})", plan, {}))
+    elif args.env:
         plan = _hip.FilterPlan(p.filter)
         arms.append(("default", plan, {}))
         for kv in args.env:

@@ -560,3 +560,31 @@ def test_config5_streaming_channel_blocks_vs_oracle():
             blocks.append(out)
         y = np.concatenate(blocks)
         assert y.dtype == out_dtype and np.abs(y - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_dead_channel_does_not_trigger_the_repair_recompute():
+    """An all-zero channel (a dead electrode) filters to exact zeros, which is what the repair pass probes
+    for; it must confirm a non-finite INPUT before recomputing (tap by tap is ~100x slower).  Checked by
+    time: a recording with a dead channel takes about as long as one without."""
+    x = synth_recording(8, 2_000_000, 22000, 130, seed=4)
+    filt = orc.generate_filter(169.2359, 2372)
+    plan = _hip.FilterPlan(filt)
+    d = torch.from_numpy(x).cuda()
+    dead = d.clone()
+    dead[3] = 0.0
+    out = torch.empty_like(d)
+
+    def timed(t):
+        plan.apply(t, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            plan.apply(t, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 3
+
+    t_live, t_dead = timed(d), timed(dead)
+    assert torch.count_nonzero(out[3]) == 0
+    assert t_dead < 2.0 * t_live + 0.2, (t_live, t_dead)
