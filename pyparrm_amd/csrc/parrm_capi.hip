@@ -27,13 +27,15 @@ int hip_fail(hipError_t err, const char *what) {
 
 namespace {
 
+constexpr int kMaxLanes = 4;
+
 struct StreamRes {
-    hipStream_t stream[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    void *d_in[2] = {nullptr, nullptr};
-    void *d_out[2] = {nullptr, nullptr};
+    hipStream_t stream[kMaxLanes] = {};
+    hipEvent_t done[kMaxLanes] = {};
+    void *d_in[kMaxLanes] = {};
+    void *d_out[kMaxLanes] = {};
     ~StreamRes() {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kMaxLanes; ++i) {
             if (d_in[i]) (void)hipFree(d_in[i]);
             if (d_out[i]) (void)hipFree(d_out[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
@@ -109,15 +111,24 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     const int64_t hw = info.half_width;
     const size_t xs = x_dtype == PARRM_F64 ? 8 : 4, ys = y_dtype == PARRM_F64 ? 8 : 4;
     if (chunk_samples <= 0) {
-        // ~1 GiB of input per chunk, but never less than a few half-widths (halo overhead <= ~12%)
-        chunk_samples = std::max<int64_t>((int64_t{1} << 30) / static_cast<int64_t>(xs) / n_chans, 16 * hw + 1024);
+        // ~256 MiB of input per chunk (PARRM_HOST_CHUNK_MB), but never less than a few half-widths (halo
+        // overhead <= ~12%)
+        int64_t mb = 256;
+        if (const char *env = getenv("PARRM_HOST_CHUNK_MB")) mb = std::max<int64_t>(1, atoll(env));
+        chunk_samples = std::max<int64_t>((mb << 20) / static_cast<int64_t>(xs) / n_chans, 16 * hw + 1024);
     }
     chunk_samples = std::min(chunk_samples, n_samples);
     const int64_t n_chunks = (n_samples + chunk_samples - 1) / chunk_samples;
     const int64_t buf_cap = chunk_samples + 2 * hw;
 
     StreamRes r;
-    const int nbuf = n_chunks > 1 ? 2 : 1;
+    // chunks in flight: the upload of chunk k+1 overlaps the kernel and the download of chunk k.  Measured
+    // (128 ch x 20 M f32 -> f32, scripts/cfg5_sweep.sh): 2 lanes x 256 MiB chunks 82 GB/s over PCIe (in + out);
+    // 3 or 4 lanes no better (the link is the limit), 1 GiB chunks 40-60 GB/s (pipeline fill and drain).
+    // PARRM_HOST_LANES / PARRM_HOST_CHUNK_MB: tuning knobs.
+    int lanes = 2;
+    if (const char *env = getenv("PARRM_HOST_LANES")) lanes = std::max(1, std::min(kMaxLanes, atoi(env)));
+    const int nbuf = static_cast<int>(std::min<int64_t>(n_chunks, lanes));
     for (int i = 0; i < nbuf; ++i) {
         PARRM_HIP_CHECK(hipStreamCreateWithFlags(&r.stream[i], hipStreamNonBlocking));
         PARRM_HIP_CHECK(hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
