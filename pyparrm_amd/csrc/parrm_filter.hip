@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(kMaxBlock) filter_stride_kernel(FilterArgs a) 
             for (int j = 0; j < G; ++j) {
                 const int rel = (m + j) * q + tid;
                 if ((m + j) * q >= len) break;
-                if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
+                if (rel < len) emit<TO, false>(a, c, s0 + rel, static_cast<double>(ring[rel & mask]), S);
                 const int relb = rel * kEl;
                 double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll

@@ -36,7 +36,9 @@ __device__ inline int valid_taps(const FilterArgs &a, int64_t n) {
     return a.tapcum[w_hi + hw + 1] - a.tapcum[w_lo + hw];
 }
 
-template <typename TO>
+// ZERO_NONFINITE: apply parrm.py:869 here (gather / repair evaluation).  The recurrence kernels pass false
+// and store non-finite results as they are: filter_repair_kernel finds them and recomputes (see below).
+template <typename TO, bool ZERO_NONFINITE = true>
 __device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc, double s) {
     double y;
     if (n >= a.hw && n + a.hw < a.n_total) {
@@ -45,7 +47,7 @@ __device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc
         const int v = valid_taps(a, n);
         y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
     }
-    if (!isfinite(y)) y = 0.0;  // parrm.py:869
+    if (ZERO_NONFINITE && !isfinite(y)) y = 0.0;  // parrm.py:869
     static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);
 }
 
@@ -66,17 +68,18 @@ __device__ inline void gather_output(const FilterArgs &a, int64_t c, int64_t n) 
 
 // Non-finite inputs and the recurrence kernels.  Those kernels carry a running tap sum per residue
 // class of a (channel, stretch); a NaN/Inf sample that enters it never leaves (NaN - NaN, Inf - Inf),
-// so from there to the end of the stretch every output of that class is non-finite and is stored as
-// 0 (parrm.py:869) -- although only the outputs whose taps reach the bad sample should be.  Because
-// the poison survives to the end of the stretch, a poisoned stretch always shows an exact 0 among its
-// last q <= 512 outputs (each residue class has one there).  This pass runs behind every recurrence
-// launch: it probes those outputs of every stretch (0.1 % of the output, L2-warm); a stretch that shows a
-// 0 where a tap is in range has its input window scanned for non-finite samples (an all-zero channel -- a
-// dead electrode -- shows zeros too), and only a stretch that has one is recomputed, tap by tap as the
-// gather kernel does.  Clean recordings pay the probe only, and
-// the hot kernels carry nothing for it -- a flag kept in the phase kernel cost it a VGPR, which is one
-// wave per SIMD at its 80-register budget.  Result: every kernel variant and every chunking returns
-// what the direct evaluation returns, on the poisoned channel too.
+// so from there to the end of the stretch every output of that class is non-finite -- although only the
+// outputs whose taps reach the bad sample should be 0 (parrm.py:869) and the others have finite values.
+// The recurrence kernels therefore do NOT apply :869 themselves: they store what they computed, and this
+// pass runs behind every recurrence launch.  Because the poison survives to the end of a stretch, a
+// stretch that produced any non-finite output shows one among its last q <= 512 outputs (each residue
+// class has one there); the pass probes those outputs of every stretch (0.1 % of the output, L2-warm) and
+// recomputes a stretch that shows one tap by tap, as the gather kernel does, zeroing exactly the outputs
+// whose taps reach a non-finite sample.  Clean recordings pay the probe only (20 us at 256 ch x 10 M), the
+// hot loops lose the per-output finiteness test (three vector instructions per output), and an all-zero
+// channel (a dead electrode) is not mistaken for a poisoned one.  A flag kept in the phase kernel instead
+// cost it a VGPR -- one wave per SIMD at its 80-register budget (9.5 -> 10.8 ms).  Result: every kernel
+// variant and every chunking returns what the direct evaluation returns, on the poisoned channel too.
 constexpr int kRepairStretchesPerBlock = 4;
 constexpr int kRepairProbe = 512;
 
@@ -92,19 +95,8 @@ __global__ void __launch_bounds__(256) filter_repair_kernel(FilterArgs a) {
         const int64_t p0 = o1 - kRepairProbe > o0 ? o1 - kRepairProbe : o0;
         int hit = 0;
         for (int64_t i = p0 + threadIdx.x; i < o1; i += blockDim.x)
-            if (y[c * a.ldy + i] == TO(0) && valid_taps(a, a.out_first + i) > 0) hit = 1;
+            if (!isfinite(static_cast<double>(y[c * a.ldy + i]))) hit = 1;
         if (!__syncthreads_or(hit)) continue;  // workgroup-uniform
-        // confirm: a non-finite sample within reach of the stretch's outputs (exact zeros alone prove nothing)
-        int64_t g0 = a.out_first + o0 - a.hw, g1 = a.out_first + o1 + a.hw;
-        if (g0 < 0) g0 = 0;
-        if (g0 < a.buf_first) g0 = a.buf_first;
-        if (g1 > a.n_total) g1 = a.n_total;
-        if (g1 > a.buf_first + a.buf_len) g1 = a.buf_first + a.buf_len;
-        const TI *row = static_cast<const TI *>(a.x) + c * a.ldx - a.buf_first;
-        int bad = 0;
-        for (int64_t g = g0 + threadIdx.x; g < g1; g += blockDim.x)
-            if (!isfinite(static_cast<double>(row[g]))) bad = 1;
-        if (!__syncthreads_or(bad)) continue;
         for (int64_t i = o0 + threadIdx.x; i < o1; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
     }
 }

@@ -435,8 +435,7 @@ __global__ void __launch_bounds__(MAXT) filter_phase3_kernel(FilterArgs a, Phase
             for (int r = 0; r < R; ++r) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    double yv = fma(-s_row[i], a.inv_taps, static_cast<double>(xo[i][r]));
-                    if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+                    const double yv = fma(-s_row[i], a.inv_taps, static_cast<double>(xo[i][r]));  // (:869 is the repair pass's)
                     const TO yo = static_cast<TO>(yv);
                     if (p.debug & 4) {
                     } else if constexpr (sizeof(TO) == 8)
@@ -453,7 +452,7 @@ __global__ void __launch_bounds__(MAXT) filter_phase3_kernel(FilterArgs a, Phase
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int rel = (m + r) * q + r0 + i;
-                    if (r0 + i < q && rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i][r]), s_row[i]);
+                    if (r0 + i < q && rel < len) emit<TO, false>(a, c, s0 + rel, static_cast<double>(xo[i][r]), s_row[i]);
                     s_row[i] += delta[i][r];
                 }
         }

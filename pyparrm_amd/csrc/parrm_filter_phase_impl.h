@@ -464,8 +464,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
                     TO *yout = yrow + (s0 + static_cast<int64_t>(m) * q);
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-                        if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+                        const double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));  // (:869 is the repair pass's)
                         (yout + static_cast<int64_t>(i) * q)[static_cast<unsigned>(r)] = static_cast<TO>(yv);
                         s_row += delta[i];
                     }
@@ -474,7 +473,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int rel = (m + i) * q + r;
-                    if (rel < len) emit<TO>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
+                    if (rel < len) emit<TO, false>(a, c, s0 + rel, static_cast<double>(xo[i]), s_row);
                     s_row += delta[i];
                 }
             }
@@ -547,8 +546,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         // 5. outputs
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));
-            if (!isfinite(yv)) yv = 0.0;  // parrm.py:869
+            const double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));  // (:869 is the repair pass's)
             const TO yo = static_cast<TO>(yv);
             if constexpr (sizeof(TO) == 8) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
