@@ -181,6 +181,7 @@ def lib() -> C.CDLL:
 
 
 def _shutdown() -> None:
+    _PLAN_CACHE.clear()  # plans free their device tables while the runtime is up
     if _lib is not None:
         _lib.parrm_hip_shutdown()
 
@@ -386,6 +387,29 @@ class FilterPlan:
             "parrm_filter_host",
         )
         return y
+
+
+_PLAN_CACHE: dict = {}
+_PLAN_CACHE_SIZE = 16
+
+
+def shared_filter_plan(filt: np.ndarray, device: int) -> FilterPlan:
+    """Plan for ``filt`` on ``device`` from a small process-wide cache keyed by the filter's content: a
+    plan is immutable (tables on the device), building one costs a stride search, a ``hipMalloc`` and a
+    synchronous upload, and the same filter comes back often -- the reference's explorer revisits
+    settings per widget event (_utils/_plotting.py:568-584), several ``PARRM`` objects of one study share
+    a period.  Plans with a forced kernel variant (tests) are never shared: this returns AUTO plans only."""
+    f = np.ascontiguousarray(filt, dtype=np.float64)
+    key = (int(device), f.shape[0], hash(f.tobytes()))
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None and np.array_equal(hit[0], f):
+        _PLAN_CACHE[key] = _PLAN_CACHE.pop(key)  # most recently used last
+        return hit[1]
+    plan = FilterPlan(f, device=device)
+    _PLAN_CACHE[key] = (f.copy(), plan)
+    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    return plan
 
 
 PINNED_OUTPUT_BYTES = 16 << 30  # results up to this size come back through page-locked memory

@@ -669,7 +669,7 @@ class PARRM:
         index = torch.cuda.current_device() if device is None or device.index is None else device.index
         plan = self._plans.get(index)
         if plan is None:
-            plan = self._plans[index] = _hip.FilterPlan(self._filter, device=index)
+            plan = self._plans[index] = _hip.shared_filter_plan(self._filter, index)
         self._last_plan = plan
         return plan
 

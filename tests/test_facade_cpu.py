@@ -310,3 +310,36 @@ def test_cache_on_device_flag_is_opt_in():
     assert p.cache_on_device is False
     p.cache_on_device = True
     assert PARRM.cache_on_device is False
+
+
+def test_online_filter_reach_and_latency_rules(golden):
+    """Host-side rules of the online mode: a tap at offset w reads sample n - w, so the reference's
+    ``"future"`` filters (w > 0, parrm.py:819-820) reach only EARLIER samples -- zero latency -- and
+    ``"past"`` filters (w <= 0, :817-818) only later ones."""
+    from pyparrm_amd.streaming import _tap_reach
+
+    g = golden("filters.npz")
+    for tag in "abcdefgh":
+        filt = g[f"{tag}_filter"]
+        hw, back, ahead = _tap_reach(filt)
+        direction = DIRS[int(g[f"{tag}_params"][3])]
+        assert hw == (filt.shape[0] - 1) // 2 and 0 <= back <= hw and 0 <= ahead <= hw
+        if direction == "future":
+            assert ahead == 0 and back > 0
+        elif direction == "past":
+            assert back == 0 and ahead > 0
+        else:
+            assert back > 0 and ahead > 0
+    with pytest.raises(ValueError, match="no taps"):
+        _tap_reach(np.array([0.0, 1.0, 0.0]))
+    with pytest.raises(ValueError, match="odd length"):
+        _tap_reach(np.zeros(4))
+    # the stream object itself needs the device
+    if not _has_gpu():
+        p = _with_period(_data((1, 400)), 2.0)
+        p.create_filter()
+        with pytest.raises(_hip.HipLibraryError):
+            p.online()
+    q = PARRM(_data(), FS, FA, verbose=False)
+    with pytest.raises(ValueError, match="The filter has not yet been created"):
+        q.online()
