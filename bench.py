@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 (default): the headline, resident f64 find_period + filter_data; cfg5: BASELINE "
                          "configs[4], float32 recording streamed from page-locked host memory, filter_data only")
+    ap.add_argument("--exchange", choices=["device", "host"], default="device",
+                    help="strong mode: the two all-gathers per stage on the process group's device collective "
+                         "(RCCL over xGMI with nccl) or staged through host memory over a gloo group (no RCCL at all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-only", action="store_true", help="time filter_data alone (config 2 style)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -226,7 +229,7 @@ def main():
     if strong:
         lo, hi = channel_shard(n_chans, rank, world)
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=0, chan_range=(lo, hi))
-        exchange = TorchExchange(dist)
+        exchange = TorchExchange(dist, via_host=args.exchange == "host")
     else:
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
     torch.cuda.synchronize()
@@ -284,7 +287,8 @@ def main():
         elif strong:
             parallelism = (f"one recording, channel blocks of {rows} rows on {world} GPUs; filter_data and the statistics "
                            "pass without exchange, candidate grids in per-rank slices over a replicated stage matrix "
-                           f"(2 all-gathers per stage on the {args.backend} process group), Nelder-Mead replicated")
+                           f"(2 all-gathers per stage, {'staged through host memory (gloo)' if args.exchange == 'host' or args.backend != 'nccl' else 'RCCL over xGMI'}), "
+                           "Nelder-Mead replicated")
         else:
             parallelism = f"{world} independent recordings, one per GPU, no exchange"
         out = {

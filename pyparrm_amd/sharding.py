@@ -90,7 +90,12 @@ class TorchExchange(Exchange):
     """``torch.distributed`` process group (one process per GPU).  With the nccl backend (= RCCL) the
     pieces travel device to device over xGMI; with gloo they are staged through host memory."""
 
-    def __init__(self, dist, group=None):
+    def __init__(self, dist, group=None, via_host: bool = False):
+        """``via_host=True`` keeps RCCL out of the data path altogether: the pieces are staged through
+        host memory over a gloo group created next to the launcher's (slower: the 51 MB stage matrix
+        of a 256-channel recording then crosses PCIe and host sockets instead of xGMI)."""
+        if via_host and dist.get_backend(group) == "nccl":
+            group = dist.new_group(backend="gloo")
         self._dist, self._group = dist, group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
