@@ -122,6 +122,9 @@ struct PhaseGeom {
     int32_t n_runs;       // full-tap runs for the per-stretch initialisation
     int32_t debug;        // ablation bits for profiling builds (PARRM_DEBUG_FLAGS); 0 in production
     int32_t wrap;         // 1: residues b in [0, q) with per-lane wrap to the previous row (guard == 0)
+    // packed float32 form only (parrm_filter_plan::phase_pack): two ring copies, one 8-byte read per tap
+    int32_t copy_o_bytes; // byte offset of copy O (row slot s at element s + 1) from copy E; rs is even, rs/2 odd
+    int32_t tab_off;      // offset (in int32) of this geometry's table within the plan's phase table
     const int32_t *tab;   // [M][2*d_pad] tap offsets per table row; [3*n_runs] (a', b_lo, b_hi); wrap: [2*d_pad] b
 };
 
@@ -162,6 +165,9 @@ struct parrm_filter_plan {
     int64_t off_tapcum = 0, off_delta = 0;
     // phase-major kernel (0 groups = not available for this filter)
     parrm_filter::PhaseGeom phase{};
+    // packed float32 form of the guarded plan (own shape and ring: two copies must fit; n_groups == 0: none);
+    // its table holds BYTE offsets and lives behind the main one in d_phase_tab
+    parrm_filter::PhaseGeom phase_pack{};
     int32_t *d_phase_tab = nullptr;
     // three-residues-per-lane form of the phase kernel (n_groups == 0: not available for this filter)
     parrm_filter::Phase3Geom phase3{};

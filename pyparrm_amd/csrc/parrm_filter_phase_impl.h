@@ -135,8 +135,21 @@ __device__ inline void tap_pair(unsigned ad_p, unsigned ad_m, TI (&v)[4]) {
 // m - a - 1 when r < b: the same address plus the constant (q*RS - 1) elements.  Which taps wrap is a
 // per-lane bit mask fixed for the kernel; every column carries one extra slot in front (a copy of
 // the last slot) so that "one slot earlier" never leaves the column.  No mirrored residues (B = 0).
-template <typename TI, typename TO, int DP, int R, bool WRAP>
+//
+// PACK (float32 recordings, R == 2, guarded form): the two rows of a tap are ONE aligned 8-byte read and
+// one packed float32 add.  With 4-byte cells the pair (slot, slot + 1) of a column is 8-byte aligned
+// only for even slots (a ds_read_b64 off its alignment is replayed at 64 cycles), so the ring is kept
+// twice: copy E holds row slot s at element s, copy O at element s + 1; the plan's table points every
+// (table row, tap) at the copy in which its pair is aligned -- a byte offset, no run-time select.  The
+// column stride RS is even with RS/2 odd there (lane stride RS*4 B keeps ds_read_b64 conflict-free).
+// PACK = 1 (float64 output, the reference's dtype rule): the tap values are still converted and summed in
+// float64 -- results unchanged to the bit, half the LDS instructions.  PACK = 2 (float32 output, the
+// build option of BASELINE configs[4]): the 14 + 14 tap values of a row are summed in float32
+// (v_pk_add_f32: both rows per instruction); the running sum S and everything downstream stay float64.
+// The reference's own float32 path is an FFT in float32 (~1e-6 of the sample scale); this keeps ~4e-7.
+template <typename TI, typename TO, int DP, int R, bool WRAP, int PACK = 0>
 __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseGeom p) {
+    static_assert(PACK == 0 || (sizeof(TI) == 4 && R == 2 && !WRAP), "PACK: float32 input, two rows, guarded form");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int kEl = static_cast<int>(sizeof(TI));
     constexpr int kElLog2 = kEl == 8 ? 3 : 2;
@@ -150,7 +163,8 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     const bool filler = r < q + 2 * B;    // fill lane: owns cell column rho (idle lanes take the halo)
     const int rho = r < q + B ? r : r - q - 2 * B;  // extended residue in [-B, q+B)
     const int n_res = q + 2 * B;
-    double *xchg = reinterpret_cast<double *>(lds_raw + align16(static_cast<size_t>(n_res) * RS * kEl));
+    const int copy_o = PACK != 0 ? p.copy_o_bytes : 0;  // byte offset of copy O from copy E
+    double *xchg = reinterpret_cast<double *>(lds_raw + (PACK != 0 ? 2 : 1) * align16(static_cast<size_t>(n_res) * RS * kEl));
     const int32_t *runs = p.tab + M * 2 * DP;
 
     const int64_t blk = blockIdx.x;
@@ -196,6 +210,11 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         *cell = v;
         if (sl < R - 1) cell[M] = v;
         if (WRAP && sl == M - 1) cell[-M] = v;  // the slot in front of slot 0
+        if constexpr (PACK != 0) {  // copy O: row slot s at element s + 1 (+ its mirrored head)
+            TI *cell_o = reinterpret_cast<TI *>(lds_raw + copy_o + fill_base + (sl + 1) * kEl);
+            *cell_o = v;
+            if (sl < R - 1) cell_o[M] = v;
+        }
     };
 
     // prologue: rows [-a_hi, NGR - a_lo) of xz, eight loads per lane in flight
@@ -296,6 +315,50 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
             accm[i] = 0.0;
         }
         if (skip_taps) {
+        } else if constexpr (PACK != 0) {
+            // one unit = the +1 and the -1 tap of a pair: two aligned 8-byte reads (both rows each), two
+            // packed adds; three register sets keep two units in flight behind the one being added
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            f32x2_t sp = {0.0f, 0.0f}, sm = {0.0f, 0.0f};  // PACK == 2: float32 sums
+            f32x2_t vp[3], vm[3];
+            auto add = [&](const f32x2_t &bp, const f32x2_t &bm) {
+                if constexpr (PACK == 2) {
+                    sp += bp;
+                    sm += bm;
+                } else {  // PACK == 1: float64 sums, as the unpacked kernel forms them
+                    accp[0] += static_cast<double>(bp.x);
+                    accp[1] += static_cast<double>(bp.y);
+                    accm[0] += static_cast<double>(bm.x);
+                    accm[1] += static_cast<double>(bm.y);
+                }
+            };
+            auto issue = [&](int u, f32x2_t &bp, f32x2_t &bm, auto wait) {
+                const unsigned ap = lds0 + static_cast<unsigned>(e[u]);       // the table holds byte offsets
+                const unsigned am = lds0 + static_cast<unsigned>(e[DP + u]);
+                if constexpr (decltype(wait)::value == 4)
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(4)"
+                                 : "=&v"(bp), "=&v"(bm) : "v"(ap), "v"(am));
+                else
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3" : "=&v"(bp), "=&v"(bm) : "v"(ap), "v"(am));
+            };
+            issue(0, vp[0], vm[0], std::integral_constant<int, -1>{});
+            if constexpr (DP > 1) issue(1, vp[1], vm[1], std::integral_constant<int, -1>{});
+#pragma unroll
+            for (int u = 2; u < DP; ++u) {
+                issue(u, vp[u % 3], vm[u % 3], std::integral_constant<int, 4>{});  // returns once unit u-2 is back
+                __builtin_amdgcn_sched_barrier(0);
+                add(vp[(u - 2) % 3], vm[(u - 2) % 3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DP > 1) add(vp[(DP - 2) % 3], vm[(DP - 2) % 3]);
+            add(vp[(DP - 1) % 3], vm[(DP - 1) % 3]);
+            if constexpr (PACK == 2) {
+                accp[0] = static_cast<double>(sp.x);
+                accp[1] = static_cast<double>(sp.y);
+                accm[0] = static_cast<double>(sm.x);
+                accm[1] = static_cast<double>(sm.y);
+            }
         } else if constexpr (R == 2) {
             // DP units of (+1 row-set, -1 row-set); two register sets: one unit in flight behind the
             // one being accumulated, one counted wait per four reads
@@ -529,6 +592,11 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
                 TI *cell = reinterpret_cast<TI *>(lds_raw + fill_base + sl_fill * kEl);
 #pragma unroll
                 for (int i = 0; i < R; ++i) cell[i] = pub[i];
+                if constexpr (PACK != 0) {
+                    TI *cell_o = reinterpret_cast<TI *>(lds_raw + copy_o + fill_base + (sl_fill + 1) * kEl);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) cell_o[i] = pub[i];
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -780,6 +848,46 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         for (int sign = 0; sign < 2; ++sign)
             for (int t = 0; t < g.d_pad; ++t) table->push_back(pick(sign == 0 ? plus : minus, t).b);
     }
+    // Packed float32 form (guarded, two rows per thread): its own shape -- two ring copies must fit next to
+    // the exchange area -- and a table of BYTE offsets into the copies: copy E holds row slot s at element
+    // s, copy O at element s + 1; a tap's pair of rows (s, s + 1) is read from the copy where it starts at
+    // an even element.
+    plan->phase_pack = PhaseGeom{};
+    if (!wrap && !getenv("PARRM_NO_F32_PACK")) {
+        PhaseGeom pk = g;
+        pk.rows = 2;
+        for (int ng : {4, 3, 2, 1}) {
+            pk.n_groups = ng;
+            pk.m_slots = 2 * ng * 2 + (g.a_hi - g.a_lo);
+            int rs2 = pk.m_slots + 2;
+            while ((rs2 & 1) || ((rs2 / 2) & 1) == 0) ++rs2;  // even, half of it odd
+            pk.rs = rs2;
+            const size_t copy_bytes = align16(static_cast<size_t>(g.q + 2 * g.guard) * rs2 * sizeof(float));
+            const size_t total = 2 * copy_bytes + static_cast<size_t>(2 * ng * g.qp) * sizeof(double);
+            if (ng * g.qp > 1024 || total > kLdsTwoBlocks) continue;
+            pk.copy_o_bytes = static_cast<int32_t>(copy_bytes);
+            pk.tab_off = static_cast<int32_t>(table->size());
+            for (int sl = 0; sl < pk.m_slots; ++sl) {
+                for (int sign = 0; sign < 2; ++sign) {
+                    for (int t = 0; t < g.d_pad; ++t) {
+                        const Split s = pick(sign == 0 ? plus : minus, t);
+                        int slot = sl - (s.a - g.a_lo);
+                        if (slot < 0) slot += pk.m_slots;
+                        const bool odd = slot & 1;
+                        const int element = -s.b * rs2 + (odd ? slot + 1 : slot);
+                        table->push_back(element * static_cast<int>(sizeof(float)) + (odd ? pk.copy_o_bytes : 0));
+                    }
+                }
+            }
+            for (size_t k = 0; k < runs.size(); k += 3) {
+                table->push_back(runs[k] - g.a_lo);
+                table->push_back(runs[k + 1]);
+                table->push_back(runs[k + 2]);
+            }
+            plan->phase_pack = pk;
+            break;
+        }
+    }
     plan->phase = g;
 }
 #endif  // PARRM_PHASE_WITH_PLAN
@@ -788,7 +896,11 @@ template <typename TI, typename TO, int DP>
 static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, PhaseGeom g, hipStream_t stream) {
     FilterArgs &a = *args;
     void (*kern)(FilterArgs, PhaseGeom) = nullptr;
-    switch (g.rows * 2 + (g.wrap ? 1 : 0)) {
+    const bool packed = g.copy_o_bytes > 0;  // float32 recordings: the packed geometry (launch_phase chose it)
+    switch (packed ? 0 : g.rows * 2 + (g.wrap ? 1 : 0)) {
+        case 0:
+            if constexpr (sizeof(TI) == 4) kern = filter_phase_kernel<TI, TO, DP, 2, false, sizeof(TO) == 4 ? 2 : 1>;
+            break;
         case 4: kern = filter_phase_kernel<TI, TO, DP, 2, false>; break;
         case 5: kern = filter_phase_kernel<TI, TO, DP, 2, true>; break;
         case 6: kern = filter_phase_kernel<TI, TO, DP, 3, false>; break;
@@ -835,7 +947,9 @@ static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, Phase
     a.n_stretch = (a.out_len + a.stretch_len - 1) / a.stretch_len;
     const int64_t blocks = a.n_chans * a.n_stretch;
     PARRM_REQUIRE(blocks <= 0x7fffffffLL, "filter: too many workgroups for one launch");
-    const size_t lds = lds_bytes(g, sizeof(TI));
+    const size_t lds = packed ? 2 * align16(static_cast<size_t>(g.q + 2 * g.guard) * g.rs * sizeof(TI)) +
+                                    static_cast<size_t>(2 * g.n_groups * g.qp) * sizeof(double)
+                              : lds_bytes(g, sizeof(TI));
     PARRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(g.n_groups * g.qp), lds, stream, a, g);
@@ -848,6 +962,17 @@ template <typename TI, typename TO>
 int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream) {
     PhaseGeom g = plan->phase;
     g.tab = plan->d_phase_tab;
+    g.copy_o_bytes = 0;
+    // float32 in AND out: the packed form where the plan has one.  (With float64 output the sums must stay
+    // float64; packed reads alone -- PACK = 1 -- measured SLOWER than the unpacked kernel, 11.1 vs 9.1 ms on
+    // 256 ch x 10 M: its two ring copies only fit a three-group shape, 18 waves per CU instead of 24, for
+    // the same vector work.)
+    if constexpr (sizeof(PARRM_PHASE_TI) == 4 && sizeof(PARRM_PHASE_TO) == 4) {
+        if (plan->phase_pack.n_groups > 0) {
+            g = plan->phase_pack;
+            g.tab = plan->d_phase_tab + g.tab_off;
+        }
+    }
     if (const char *env = getenv("PARRM_DEBUG_FLAGS")) g.debug = atoi(env);  // profiling ablations only
     switch (g.d_pad) {
         case 4: return launch_phase_r<TI, TO, 4>(plan, a, g, stream);
