@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         if constexpr (PACK != 0) {  // copy O: row slot s at element s + 1 (+ its mirrored head)
             TI *cell_o = reinterpret_cast<TI *>(lds_raw + copy_o + fill_base + (sl + 1) * kEl);
             *cell_o = v;
-            if (sl < R - 1) cell_o[M] = v;
+            if (sl < R - 1 && !(M & 1)) cell_o[M] = v;  // (odd M: that element is never read, see the planner)
         }
     };
 
@@ -859,7 +859,10 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
         for (int ng : {4, 3, 2, 1}) {
             pk.n_groups = ng;
             pk.m_slots = 2 * ng * 2 + (g.a_hi - g.a_lo);
-            int rs2 = pk.m_slots + 2;
+            // copy E uses elements 0 .. M (mirrored head at M); copy O holds row s at element s + 1 and is read
+            // for odd s only: elements up to M + 1, or up to M when M is odd (the pair starting at the last
+            // slot M - 1 is then an even one and comes from copy E)
+            int rs2 = (pk.m_slots & 1) ? pk.m_slots + 1 : pk.m_slots + 2;
             while ((rs2 & 1) || ((rs2 / 2) & 1) == 0) ++rs2;  // even, half of it odd
             pk.rs = rs2;
             const size_t copy_bytes = align16(static_cast<size_t>(g.q + 2 * g.guard) * rs2 * sizeof(float));
@@ -963,11 +966,10 @@ int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t strea
     PhaseGeom g = plan->phase;
     g.tab = plan->d_phase_tab;
     g.copy_o_bytes = 0;
-    // float32 in AND out: the packed form where the plan has one.  (With float64 output the sums must stay
-    // float64; packed reads alone -- PACK = 1 -- measured SLOWER than the unpacked kernel, 11.1 vs 9.1 ms on
-    // 256 ch x 10 M: its two ring copies only fit a three-group shape, 18 waves per CU instead of 24, for
-    // the same vector work.)
-    if constexpr (sizeof(PARRM_PHASE_TI) == 4 && sizeof(PARRM_PHASE_TO) == 4) {
+    // float32 recordings: the packed form where the plan has one.  float32 output sums the taps of a row in
+    // float32 (PACK = 2: 8.6 -> 6.0 ms on 256 ch x 10 M); float64 output keeps float64 sums (PACK = 1: same
+    // values, half the LDS reads, 9.2 -> 8.9 ms).  PARRM_NO_F32_PACK at plan time turns both off.
+    if constexpr (sizeof(PARRM_PHASE_TI) == 4) {
         if (plan->phase_pack.n_groups > 0) {
             g = plan->phase_pack;
             g.tab = plan->d_phase_tab + g.tab_off;
