@@ -6,7 +6,7 @@ y = torch.empty((256, 10_000_000), dtype=torch.float64, device="cuda")
 p = PARRM(np.zeros((1, 10_000_000)), 22000.0, 130.0, verbose=False); p._period = np.float64(22000.0/130.0*(1+3e-5)); p.create_filter()
 plans = {}
 plan = _hip.FilterPlan(p.filter)
-plans = {"unpacked (default for float64 output)": {}, "packed reads, f64 sums": {"PARRM_F32_PACK_F64OUT": "1"}}
+plans = {"packed reads, f64 sums (default)": {}}
 res = {k: [] for k in plans}
 for rnd in range(8):
     for k, env in plans.items():
