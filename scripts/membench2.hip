@@ -1,3 +1,9 @@
+// CAUTION (round 2): only the `walk` modes 0/1/2/3 of this file produced usable numbers (8 B vs 16 B per
+// lane: within 2 % of each other).  The later kernels here (walk3, walk4: per-lane bounds tests inside the
+// loop) compile to vmcnt(0) waits, branches and scratch spills -- their 12-28 ms measure hipcc, not the
+// memory system.  scripts/membench3.hip is the hand-shaped replacement (buffer descriptors, counted waits)
+// and the one DESIGN.md 4.2 quotes.
+//
 // Micro-benchmark 2: which global-memory access shape should the phase kernel's load / store legs
 // use?  One workgroup walks one (channel, stretch) in iterations of NGR rows of q doubles, as the
 // filter kernel does (per-iteration barrier, loads requested D iterations ahead, 2 workgroups per CU

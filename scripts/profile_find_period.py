@@ -26,7 +26,7 @@ calls = []
 orig = _hip.fit_errors
 
 
-def wrapped(y, idx, periods, bw, lam, ws=None):
+def wrapped(y, idx, periods, bw, lam, ws=None, grid_periods=0):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = orig(y, idx, periods, bw, lam, ws)
