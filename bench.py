@@ -82,7 +82,15 @@ def parse():
 
 def spawn_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start the N ranks as child processes.  Nothing in
-    this process has touched the GPU yet (no torch import, no HIP call), and nothing will."""
+    this process has touched the GPU yet (no HIP call; counting devices does not initialise the runtime),
+    and nothing will.  A rank that dies takes the others with it -- they would wait for it forever."""
+    if not args.single_device:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -91,8 +99,19 @@ def spawn_ranks(args) -> int:
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
-    return next((c for c in codes if c != 0), 0)
+    status = 0
+    while procs:
+        time.sleep(0.2)
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and status == 0:
+                status = code
+                for other in procs:  # the exact processes started above
+                    other.terminate()
+    return status
 
 
 def run_cpu_baseline():

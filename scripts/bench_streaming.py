@@ -54,9 +54,11 @@ def main():
         _hip.unpin_host(arr)
     d = torch.from_numpy(x[:4]).cuda()
     ref = plan.apply(d, out_dtype=torch.float32 if args.out == "f32" else torch.float64).cpu().numpy()
-    err = np.abs(ref - y[:4]).max()
+    err = np.abs(ref.astype(np.float64) - y[:4]).max()
     print("max |streamed - resident| on 4 channels:", err)
-    assert err == 0.0
+    # float64 sums (f32 -> f64) are chunk-invariant to the bit; the packed float32 sums of the f32 -> f32
+    # form depend on where a stretch starts, at the 1e-7 level
+    assert err <= (0.0 if args.out == "f64" else 2e-6 * np.abs(ref).max())
 
 
 if __name__ == "__main__":
