@@ -114,6 +114,16 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
                               int64_t buf_len, int64_t out_first, int64_t out_len,
                               int64_t n_total, int64_t ldx, int64_t ldy, void *stream);
 
+/* Channel-block form (one recording sharded over GPUs by channel blocks, parrm.py:861-866 filters every
+ * channel independently): filters `n_chans` channels of a recording that has `total_chans` in all, cutting
+ * the time axis exactly as a call on the whole recording would -- so every channel's output is
+ * bit-identical to the unsharded call's, whatever the block size.  parrm_filter_apply_window is the
+ * total_chans == n_chans case. */
+int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int x_dtype, void *d_y,
+                             int y_dtype, int64_t n_chans, int64_t total_chans, int64_t buf_first,
+                             int64_t buf_len, int64_t out_first, int64_t out_len, int64_t n_total,
+                             int64_t ldx, int64_t ldy, void *stream);
+
 /* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host page-locks the
  * caller's buffers itself when they are not locked yet, which costs ~20 ms per GiB per call (more
  * than moving the data); a caller that filters the same recording repeatedly -- the reference's

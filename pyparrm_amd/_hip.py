@@ -31,6 +31,7 @@ SYMBOLS = (
     "parrm_filter_plan_set_kernel",
     "parrm_filter_apply",
     "parrm_filter_apply_window",
+    "parrm_filter_apply_block",
     "parrm_filter_host",
     "parrm_host_pin",
     "parrm_host_unpin",
@@ -147,6 +148,8 @@ def lib() -> C.CDLL:
         L.parrm_filter_apply.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
         L.parrm_filter_apply_window.restype = i32
         L.parrm_filter_apply_window.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, vp]
+        L.parrm_filter_apply_block.restype = i32
+        L.parrm_filter_apply_block.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp]
         L.parrm_filter_host.restype = i32
         L.parrm_filter_host.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, i64]
         L.parrm_host_pin.restype = i32
@@ -303,8 +306,10 @@ class FilterPlan:
     def set_kernel(self, kernel: int) -> None:
         check(lib().parrm_filter_plan_set_kernel(self._h, kernel), "parrm_filter_plan_set_kernel")
 
-    def apply(self, x, out=None, out_dtype=None):
-        """y = filter(x) for a device-resident recording ``x[C, N]`` (f32/f64)."""
+    def apply(self, x, out=None, out_dtype=None, total_chans=None):
+        """y = filter(x) for a device-resident recording ``x[C, N]`` (f32/f64).  ``total_chans``: ``x`` is
+        a channel block of a recording with that many channels; the time axis is then cut as for the whole
+        recording, so the block's output is bit-identical to the same rows of an unsharded call."""
         torch = require_gpu()
         _check_rows(x, "x")
         self._check_device(x)
@@ -325,11 +330,12 @@ class FilterPlan:
                 events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 events[0].record()  # torch's current stream == the stream passed to the launch
             check(
-                lib().parrm_filter_apply(
+                lib().parrm_filter_apply_block(
                     self._h, x.data_ptr(), _dtype_code(x), out.data_ptr(), _dtype_code(out),
-                    n_chans, n_samples, ldx, ldy, _stream_ptr(torch),
+                    n_chans, max(int(total_chans or 0), n_chans), 0, n_samples, 0, n_samples, n_samples,
+                    ldx, ldy, _stream_ptr(torch),
                 ),
-                "parrm_filter_apply",
+                "parrm_filter_apply_block",
             )
             if events is not None:
                 events[1].record()
@@ -353,6 +359,7 @@ class FilterPlan:
                     max(x.stride(0), x.shape[1]), max(out.stride(0), out_len), _stream_ptr(torch),
                 ),
                 "parrm_filter_apply_window",
+    "parrm_filter_apply_block",
             )
         return out
 

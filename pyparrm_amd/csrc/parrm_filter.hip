@@ -292,7 +292,7 @@ int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStr
     a.ring_mask = (1 << ring_log2) - 1;
     // stretch: ~64K samples, a whole number of fills; shrink while the grid would not fill the chip
     int64_t rows = std::max<int64_t>(G, (65536 / q) / G * G);
-    auto blocks_for = [&](int64_t r) { return a.n_chans * ((a.out_len + r * q - 1) / (r * q)); };
+    auto blocks_for = [&](int64_t r) { return a.plan_chans * ((a.out_len + r * q - 1) / (r * q)); };
     while (rows > 4 * G && blocks_for(rows) < 2048) rows = std::max<int64_t>(G, (rows / 2) / G * G);
     a.stretch_len = rows * q;
     a.n_stretch = (a.out_len + a.stretch_len - 1) / a.stretch_len;
@@ -457,6 +457,15 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
                               int y_dtype, int64_t n_chans, int64_t buf_first, int64_t buf_len,
                               int64_t out_first, int64_t out_len, int64_t n_total, int64_t ldx,
                               int64_t ldy, void *stream) {
+    return parrm_filter_apply_block(plan, d_x, x_dtype, d_y, y_dtype, n_chans, n_chans, buf_first, buf_len, out_first,
+                                    out_len, n_total, ldx, ldy, stream);
+}
+
+int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int x_dtype, void *d_y, int y_dtype,
+                             int64_t n_chans, int64_t total_chans, int64_t buf_first, int64_t buf_len,
+                             int64_t out_first, int64_t out_len, int64_t n_total, int64_t ldx, int64_t ldy,
+                             void *stream) {
+    PARRM_REQUIRE(total_chans >= n_chans, "filter_apply: a channel block cannot be larger than its recording");
     PARRM_REQUIRE(plan, "filter_apply: NULL plan");
     PARRM_REQUIRE(n_chans >= 0 && out_len >= 0 && n_total >= 0 && buf_len >= 0, "filter_apply: negative size");
     if (n_chans == 0 || out_len == 0) return PARRM_OK;
@@ -482,6 +491,7 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
     a.x = d_x;
     a.y = d_y;
     a.n_chans = n_chans;
+    a.plan_chans = total_chans;
     a.buf_first = buf_first;
     a.buf_len = buf_len;
     a.out_first = out_first;
@@ -497,7 +507,7 @@ int parrm_filter_apply_window(const parrm_filter_plan *plan, const void *d_x, in
     a.hw = static_cast<int32_t>(plan->hw);
     a.n_taps = static_cast<int32_t>(plan->n_taps);
     a.inv_taps = 1.0 / static_cast<double>(plan->n_taps);
-    const int kernel = resolve_kernel(plan, n_chans, out_len);
+    const int kernel = resolve_kernel(plan, total_chans, out_len);
     hipStream_t s = parrm::as_stream(stream);
     if (x_dtype == PARRM_F64) return launch<double, double>(plan, a, kernel, s);
     if (y_dtype == PARRM_F64) return launch<float, double>(plan, a, kernel, s);

@@ -11,6 +11,7 @@ struct FilterArgs {
     const void *x;
     void *y;
     int64_t n_chans;
+    int64_t plan_chans;          // channels the stretch geometry is planned for (>= n_chans: a channel block of a sharded recording is cut like the whole recording, so every channel's result is bit-identical)
     int64_t buf_first, buf_len;  // samples [buf_first, buf_first+buf_len) are addressable in x
     int64_t out_first, out_len;  // outputs to produce
     int64_t n_total;             // length of the whole recording (edge logic)

@@ -924,7 +924,7 @@ static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, Phase
     int64_t target = 262144;
     if (const char *env = getenv("PARRM_STRETCH_SAMPLES")) target = std::max<int64_t>(atoll(env), g.q);  // tuning knob
     int64_t rows = std::max<int64_t>(ngr, (target / g.q) / ngr * ngr);
-    auto blocks_for = [&](int64_t r) { return a.n_chans * ((a.out_len + r * g.q - 1) / (r * g.q)); };
+    auto blocks_for = [&](int64_t r) { return a.plan_chans * ((a.out_len + r * g.q - 1) / (r * g.q)); };
     if (blocks_for(rows) < 4096 && !getenv("PARRM_STRETCH_SAMPLES")) {
         const double prologue = 16384.0;
         const int64_t resident = 512;

@@ -637,7 +637,7 @@ class PARRM:
                 filtered = self._plan_for(None).apply_host(np.ascontiguousarray(data))
             else:
                 x = self._device_recording(data)
-                y = self._plan_for(x.device).apply(x)
+                y = self._plan_for(x.device).apply(x, total_chans=self._total_chans(x))
                 filtered = _hip.to_host_numpy(y) if isinstance(data, np.ndarray) else y
         finally:
             self._end_call()
@@ -661,6 +661,10 @@ class PARRM:
             dtype = np.float32 if str(getattr(self._data, "dtype", "")).endswith("float32") else np.float64
         return OnlineFilter(self._filter, self._n_chans if n_chans is None else n_chans, dtype=dtype,
                             out_dtype=out_dtype, device=device)
+
+    def _total_chans(self, x):
+        """Channels of the whole recording ``x`` is a block of (``sharding.ShardedPARRM`` overrides)."""
+        return int(x.shape[0])
 
     def _plan_for(self, device):
         """Filter plan on ``device`` (default: the current one).  The plan's tables live in that

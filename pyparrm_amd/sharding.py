@@ -159,6 +159,23 @@ class ShardedPARRM(PARRM):
         clone._exchange = self._exchange  # a communicator is shared, not copied
         return clone
 
+    def _learn_block_sizes(self, device) -> None:
+        torch = _hip.require_gpu()
+        if self._block_sizes is None:
+            mine = torch.tensor([self._n_chans], dtype=torch.int64, device=device)
+            self._block_sizes = [int(t.item()) for t in self._exchange.all_gather(mine)]
+            if min(self._block_sizes) < 1:
+                raise ValueError("every rank of a sharded recording needs at least one channel")
+
+    def _total_chans(self, x):
+        """filter_data cuts the time axis as for the WHOLE recording (``parrm_filter_apply_block``), so a
+        block's output is bit-identical to the same rows of the unsharded result.  Applies to the
+        object's own block; any other array is filtered as a recording of its own."""
+        if self._exchange.world_size == 1 or x.shape[0] != self._n_chans:
+            return int(x.shape[0])
+        self._learn_block_sizes(x.device)
+        return sum(self._block_sizes)
+
     # stage columns of ALL channels on every rank
     def _stage_matrix(self, indices: np.ndarray):
         torch = _hip.require_gpu()
@@ -166,11 +183,7 @@ class ShardedPARRM(PARRM):
         ex = self._exchange
         if ex.world_size == 1:
             return y_local, d_idx
-        if self._block_sizes is None:
-            mine = torch.tensor([self._n_chans], dtype=torch.int64, device=y_local.device)
-            self._block_sizes = [int(t.item()) for t in ex.all_gather(mine)]
-            if min(self._block_sizes) < 1:
-                raise ValueError("every rank of a sharded search needs at least one channel")
+        self._learn_block_sizes(y_local.device)
         widest = max(self._block_sizes)
         padded = torch.zeros((y_local.shape[0], widest), dtype=torch.float64, device=y_local.device)
         padded[:, : self._n_chans] = y_local

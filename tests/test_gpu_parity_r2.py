@@ -617,3 +617,19 @@ def test_phase3_kernel_form_matches_the_oracle(monkeypatch, dtype, out_dtype):
             assert np.abs(part - ref[:, o0:o0 + olen]).max() <= tol * np.abs(ref).max()
     monkeypatch.delenv("PARRM_PHASE3")
     assert _hip.FilterPlan(filt).info.phase_residues == 1  # opt-in only
+
+
+def test_channel_blocks_are_cut_like_the_whole_recording():
+    """The launch picks its stretch length from the channel count (short or narrow recordings get fewer,
+    longer stretches), so a channel block filtered on its own would be cut differently from the whole
+    recording and differ in the last bits.  ``total_chans`` (``parrm_filter_apply_block``) plans a block as
+    the whole recording: bit-identical rows, f64 and the packed f32 form alike (configs[3])."""
+    rng = np.random.default_rng(17)
+    filt = orc.generate_filter(169.2359, 2372)
+    plan = _hip.FilterPlan(filt)
+    for dtype, out_dtype in ((torch.float64, torch.float64), (torch.float32, torch.float32)):
+        x = torch.from_numpy(rng.standard_normal((48, 1_500_000))).to(dtype).cuda()
+        whole = plan.apply(x, out_dtype=out_dtype)
+        for rows in (6, 16):
+            parts = [plan.apply(x[lo:lo + rows].contiguous(), out_dtype=out_dtype, total_chans=48) for lo in range(0, 48, rows)]
+            assert torch.equal(torch.cat(parts), whole), (dtype, rows)

@@ -111,7 +111,7 @@ def _install_oracle_device(torch, orc):
         def __init__(self, filt, device=None):
             self.filt, self.device = filt, device
 
-        def apply(self, x, out=None, out_dtype=None):
+        def apply(self, x, out=None, out_dtype=None, total_chans=None):
             return torch.from_numpy(orc.filter_data_direct(x.numpy(), self.filt))
 
     def gather(x, idx, scale, ob):
