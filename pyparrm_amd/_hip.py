@@ -359,7 +359,6 @@ class FilterPlan:
                     max(x.stride(0), x.shape[1]), max(out.stride(0), out_len), _stream_ptr(torch),
                 ),
                 "parrm_filter_apply_window",
-    "parrm_filter_apply_block",
             )
         return out
 
