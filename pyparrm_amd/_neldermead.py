@@ -73,6 +73,24 @@ class _Start:
         self.iterations = 0  # 0: initial simplex not evaluated yet
         self.done = False
 
+    @staticmethod
+    def _trial_points(xbar, worst):
+        """(reflection, outside contraction, inside contraction) of the simplex {xbar, worst}."""
+        return ((1 + RHO) * xbar - RHO * worst,
+                (1 + PSI * RHO) * xbar - PSI * RHO * worst,
+                (1 - PSI) * xbar + PSI * worst)
+
+    def lookahead(self):
+        """Abscissae of the step AFTER the next one, should the next one accept its inside contraction
+        -- what it does in ~9 of 10 steps -- with the new vertex ending up as either the better or the
+        worse of the two.  A caller with few runs in flight adds them to the batch: when the guess holds
+        the following step finds its values already there and costs no device round trip."""
+        if self.iterations == 0:
+            return []
+        best, worst = self.sim
+        new = (1 - PSI) * best + PSI * worst
+        return list(self._trial_points(new, best)) + list(self._trial_points(best, new))
+
     # -- the abscissae the next step may need -------------------------------------------------
     def wanted(self):
         if self.iterations == 0:
@@ -172,27 +190,41 @@ class _Start:
         return np.array([self.sim[0]], dtype=np.float64), float(fmin_), self.iterations, self.fcalls
 
 
+LOOKAHEAD_RUNS = 2  # at most this many runs in flight: also evaluate the likely next step's points
+
+
 def fmin_lockstep_requests(starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None):
     """Generator form of :func:`fmin_lockstep`: yields the float64 array of abscissae of each batch
     and expects their objective values to be sent back; returns (``StopIteration.value``) the list of
     ``(xopt[1], fopt, iterations, funcalls)``.  Lets a caller advance several independent searches
-    together and evaluate all their batches in one device call."""
+    together and evaluate all their batches in one device call.
+
+    Values stay in a table across steps, and while only one or two runs are in flight (the final polish
+    of a period search is a single run of ~35 dependent steps) each batch also carries the points of the
+    likely FOLLOWING step (``_Start.lookahead``): a step whose points are all known already costs no
+    round trip.  Which values a step reads, and so every decision, is unchanged."""
     runs = [_Start(x0, xtol, ftol, maxiter, maxfun) for x0 in starts]
+    table = {}
     while True:
         active = [run for run in runs if not run.done]
         if not active:
             break
-        points = sorted({x for run in active for x in run.wanted() if x == x})
-        values = yield np.array(points, dtype=np.float64)
-        table = dict(zip(points, np.asarray(values, dtype=np.float64).tolist()))
+        want = {x for run in active for x in run.wanted() if x == x}
+        need = sorted(x for x in want if x not in table)
+        if need:
+            if len(active) <= LOOKAHEAD_RUNS:
+                ahead = {x for run in active for x in run.lookahead() if x == x and x not in table}
+                need = sorted(set(need) | ahead)
+            values = yield np.array(need, dtype=np.float64)
+            table.update(zip(need, np.asarray(values, dtype=np.float64).tolist()))
         pending = active
         while pending:
             missing, still = set(), []
             for run in pending:
                 try:
                     run.advance(table)
-                except _Missing as need:
-                    missing.add(need.x)
+                except _Missing as miss:
+                    missing.add(miss.x)
                     still.append(run)
             if not missing:
                 break
@@ -200,6 +232,8 @@ def fmin_lockstep_requests(starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=No
             values = yield np.array(extra, dtype=np.float64)
             table.update(zip(extra, np.asarray(values, dtype=np.float64).tolist()))
             pending = still
+        if len(table) > 4096:  # (a search never gets near this; keeps a pathological caller bounded)
+            table = {x: table[x] for x in want if x in table}
     return [run.result() for run in runs]
 
 
