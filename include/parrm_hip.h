@@ -124,17 +124,21 @@ int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int
                              int64_t buf_len, int64_t out_first, int64_t out_len, int64_t n_total,
                              int64_t ldx, int64_t ldy, void *stream);
 
-/* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host page-locks the
- * caller's buffers itself when they are not locked yet, which costs ~20 ms per GiB per call (more
- * than moving the data); a caller that filters the same recording repeatedly -- the reference's
- * parameter explorer re-filters on every widget event (_utils/_plotting.py:568-584) -- locks it
- * once instead.  Buffers that already are pinned (e.g. by the caller's allocator) are detected and
- * left alone by both entry points. */
+/* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host uses buffers that are
+ * already page-locked in place (the fast path); a buffer that is not is locked by the call itself only
+ * when it is >= 64 MiB (~20 ms per GiB per call -- more than moving the data), and goes through staging
+ * buffers of the call's own otherwise (a lock covers whole pages and HIP does not count references, so a
+ * small buffer's first and last page may belong to someone else's allocation as well).  A caller that
+ * filters the same recording repeatedly -- the reference's parameter explorer re-filters on every widget
+ * event (_utils/_plotting.py:568-584) -- locks it once with parrm_host_pin; the buffer must then stay
+ * allocated until parrm_host_unpin, and nothing else may lock or unlock a range that shares a page with
+ * it meanwhile.  Buffers that already are pinned (e.g. by the caller's allocator) are detected and left
+ * alone by both entry points. */
 int parrm_host_pin(void *h_ptr, size_t bytes);
 int parrm_host_unpin(void *h_ptr);
 
 /* Host-resident recording, streamed through the device in time chunks of `chunk_samples`
- * (0 = pick) with pinned double buffers and two streams; synchronous. */
+ * (0 = pick) on two streams with double buffers; synchronous. */
 int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtype, void *h_y,
                       int y_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
                       int64_t ldy, int64_t chunk_samples);

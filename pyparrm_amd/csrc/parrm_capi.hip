@@ -34,10 +34,14 @@ struct StreamRes {
     hipEvent_t done[kMaxLanes] = {};
     void *d_in[kMaxLanes] = {};
     void *d_out[kMaxLanes] = {};
+    void *h_in[kMaxLanes] = {};   // library-owned page-locked staging (see parrm_filter_host)
+    void *h_out[kMaxLanes] = {};
     ~StreamRes() {
         for (int i = 0; i < kMaxLanes; ++i) {
             if (d_in[i]) (void)hipFree(d_in[i]);
             if (d_out[i]) (void)hipFree(d_out[i]);
+            if (h_in[i]) (void)hipHostFree(h_in[i]);
+            if (h_out[i]) (void)hipHostFree(h_out[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
             if (stream[i]) (void)hipStreamDestroy(stream[i]);
         }
@@ -68,11 +72,6 @@ int parrm_hip_device_count(int *count) {
     return PARRM_OK;
 }
 
-// Time-chunked streaming: chunk k covers outputs [k*chunk, (k+1)*chunk) and is uploaded with a
-// half-width halo on each side (stencil locality, SURVEY.md 5 "long-context").  Two streams, two
-// device buffer pairs: upload/compute/download of chunk k+1 overlaps chunk k.  The host buffers are
-// page-locked for the duration of the call so the copies are true async DMA.
-// true when the runtime already knows `p` as page-locked host memory
 static bool is_pinned_host(const void *p) {
     hipPointerAttribute_t attr{};
     const hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -97,6 +96,23 @@ int parrm_host_unpin(void *h_ptr) {
     return PARRM_OK;
 }
 
+// Time-chunked streaming: chunk k covers outputs [k*chunk, (k+1)*chunk) and is uploaded with a
+// half-width halo on each side (stencil locality, SURVEY.md 5 "long-context").  Two streams, two
+// device buffer pairs: upload/compute/download of chunk k+1 overlaps chunk k.
+//
+// How the caller's host buffers reach the copy engines, per buffer:
+//   * already page-locked (hipHostMalloc, hipHostRegister, parrm_host_pin, a torch pinned tensor): used
+//     in place -- the fast path (80+ GB/s both ways);
+//   * not locked and >= 64 MiB: locked in place for the duration of the call (hipHostRegister; ~20 ms per
+//     GiB) and released on every exit path;
+//   * not locked and smaller (or the lock was refused): the chunks go through page-locked staging
+//     buffers the call owns, filled and drained by the calling thread.  A registration covers whole
+//     pages and HIP does not count references (a second hipHostRegister of a range succeeds and ONE
+//     hipHostUnregister drops the mapping -- scripts/exp_host_register.py), so locking a small buffer
+//     that shares its first or last page with another live allocation (glibc serves arrays of up to
+//     32 MiB from the heap once its dynamic mmap threshold has grown) is not the library's to do:
+//     the round-2 filter fuzz met a GPU page fault at a heap address that way, ~140 cases into a
+//     run.  Buffers of >= 64 MiB are always their own mapping.
 int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtype, void *h_y, int y_dtype,
                       int64_t n_chans, int64_t n_samples, int64_t ldx, int64_t ldy, int64_t chunk_samples) {
     PARRM_REQUIRE(plan && h_x && h_y, "filter_host: NULL argument");
@@ -129,25 +145,55 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     int lanes = 2;
     if (const char *env = getenv("PARRM_HOST_LANES")) lanes = std::max(1, std::min(kMaxLanes, atoi(env)));
     const int nbuf = static_cast<int>(std::min<int64_t>(n_chunks, lanes));
-    for (int i = 0; i < nbuf; ++i) {
-        PARRM_HIP_CHECK(hipStreamCreateWithFlags(&r.stream[i], hipStreamNonBlocking));
-        PARRM_HIP_CHECK(hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
-        PARRM_HIP_CHECK(hipMalloc(&r.d_in[i], static_cast<size_t>(n_chans * buf_cap) * xs));
-        PARRM_HIP_CHECK(hipMalloc(&r.d_out[i], static_cast<size_t>(n_chans * chunk_samples) * ys));
-    }
-    // page-lock the caller's buffers (no staging copy); unlock on every exit path
     const size_t x_bytes = static_cast<size_t>((n_chans - 1) * ldx + n_samples) * xs;
     const size_t y_bytes = static_cast<size_t>((n_chans - 1) * ldy + n_samples) * ys;
-    const bool pin_x = !is_pinned_host(h_x) &&
-                       hipHostRegister(const_cast<void *>(h_x), x_bytes, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_y = !is_pinned_host(h_y) && hipHostRegister(h_y, y_bytes, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();  // a refused registration only costs bandwidth
+    constexpr size_t kLockInPlaceMin = size_t{64} << 20;
+    bool locked_x = false, locked_y = false;  // locked by this call: released below
+    auto usable_in_place = [&](const void *p, size_t bytes, bool *locked_here) {
+        if (is_pinned_host(p)) return true;
+        if (bytes >= kLockInPlaceMin && !getenv("PARRM_HOST_NO_LOCK")) {
+            if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
+                *locked_here = true;
+                return true;
+            }
+            (void)hipGetLastError();  // refused (lock limit): staged instead
+        }
+        return false;
+    };
+    const bool direct_x = usable_in_place(h_x, x_bytes, &locked_x);
+    const bool direct_y = usable_in_place(h_y, y_bytes, &locked_y);
     auto unpin = [&]() {
-        if (pin_x) (void)hipHostUnregister(const_cast<void *>(h_x));
-        if (pin_y) (void)hipHostUnregister(h_y);
+        if (locked_x) (void)hipHostUnregister(const_cast<void *>(h_x));
+        if (locked_y) (void)hipHostUnregister(h_y);
+    };
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < nbuf && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&r.stream[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(&r.d_in[i], static_cast<size_t>(n_chans * buf_cap) * xs);
+        if (e == hipSuccess) e = hipMalloc(&r.d_out[i], static_cast<size_t>(n_chans * chunk_samples) * ys);
+        if (e == hipSuccess && !direct_x) e = hipHostMalloc(&r.h_in[i], static_cast<size_t>(n_chans * buf_cap) * xs, hipHostMallocDefault);
+        if (e == hipSuccess && !direct_y) e = hipHostMalloc(&r.h_out[i], static_cast<size_t>(n_chans * chunk_samples) * ys, hipHostMallocDefault);
+    }
+    if (e != hipSuccess) {
+        unpin();
+        return parrm::hip_fail(e, "filter_host: buffers");
+    }
+
+    // staged output: the chunk a lane produced last waits in its h_out until the lane is reused (or the end)
+    int64_t pend_o0[kMaxLanes] = {}, pend_len[kMaxLanes] = {};
+    auto drain = [&](int b) -> hipError_t {
+        if (direct_y || pend_len[b] == 0) return hipSuccess;
+        const hipError_t es = hipEventSynchronize(r.done[b]);
+        if (es != hipSuccess) return es;
+        const size_t row = static_cast<size_t>(pend_len[b]) * ys;
+        for (int64_t c = 0; c < n_chans; ++c)
+            memcpy(static_cast<char *>(h_y) + (static_cast<size_t>(c) * ldy + pend_o0[b]) * ys,
+                   static_cast<const char *>(r.h_out[b]) + static_cast<size_t>(c) * row, row);
+        pend_len[b] = 0;
+        return hipSuccess;
     };
 
-    hipError_t e = hipSuccess;
     for (int64_t k = 0; k < n_chunks && e == hipSuccess && rc == PARRM_OK; ++k) {
         const int b = static_cast<int>(k % nbuf);
         const int64_t o0 = k * chunk_samples;
@@ -155,23 +201,45 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
         const int64_t b0 = std::max<int64_t>(o0 - hw, 0);
         const int64_t b1 = std::min<int64_t>(o0 + olen + hw, n_samples);
         const int64_t blen = b1 - b0;
-        // stream order on r.stream[b] already serialises reuse of buffer pair b
-        e = hipMemcpy2DAsync(r.d_in[b], static_cast<size_t>(blen) * xs,
-                             static_cast<const char *>(h_x) + static_cast<size_t>(b0) * xs,
-                             static_cast<size_t>(ldx) * xs, static_cast<size_t>(blen) * xs,
-                             static_cast<size_t>(n_chans), hipMemcpyHostToDevice, r.stream[b]);
+        // stream order on r.stream[b] already serialises reuse of the device buffer pair b
+        if (direct_x) {
+            e = hipMemcpy2DAsync(r.d_in[b], static_cast<size_t>(blen) * xs,
+                                 static_cast<const char *>(h_x) + static_cast<size_t>(b0) * xs,
+                                 static_cast<size_t>(ldx) * xs, static_cast<size_t>(blen) * xs,
+                                 static_cast<size_t>(n_chans), hipMemcpyHostToDevice, r.stream[b]);
+        } else {
+            // the lane's previous upload has left h_in once its download event has fired
+            if (k >= nbuf) e = hipEventSynchronize(r.done[b]);
+            if (e != hipSuccess) break;
+            const size_t row = static_cast<size_t>(blen) * xs;
+            for (int64_t c = 0; c < n_chans; ++c)
+                memcpy(static_cast<char *>(r.h_in[b]) + static_cast<size_t>(c) * row,
+                       static_cast<const char *>(h_x) + (static_cast<size_t>(c) * ldx + b0) * xs, row);
+            e = hipMemcpyAsync(r.d_in[b], r.h_in[b], static_cast<size_t>(n_chans) * row, hipMemcpyHostToDevice, r.stream[b]);
+        }
+        if (e != hipSuccess) break;
+        e = drain(b);  // (after the upload was queued: the copy-out overlaps it)
         if (e != hipSuccess) break;
         rc = parrm_filter_apply_window(plan, r.d_in[b], x_dtype, r.d_out[b], y_dtype, n_chans, b0, blen, o0, olen,
                                        n_samples, blen, olen, r.stream[b]);
         if (rc != PARRM_OK) break;
-        e = hipMemcpy2DAsync(static_cast<char *>(h_y) + static_cast<size_t>(o0) * ys, static_cast<size_t>(ldy) * ys,
-                             r.d_out[b], static_cast<size_t>(olen) * ys, static_cast<size_t>(olen) * ys,
-                             static_cast<size_t>(n_chans), hipMemcpyDeviceToHost, r.stream[b]);
+        if (direct_y) {
+            e = hipMemcpy2DAsync(static_cast<char *>(h_y) + static_cast<size_t>(o0) * ys, static_cast<size_t>(ldy) * ys,
+                                 r.d_out[b], static_cast<size_t>(olen) * ys, static_cast<size_t>(olen) * ys,
+                                 static_cast<size_t>(n_chans), hipMemcpyDeviceToHost, r.stream[b]);
+        } else {
+            e = hipMemcpyAsync(r.h_out[b], r.d_out[b], static_cast<size_t>(n_chans * olen) * ys, hipMemcpyDeviceToHost,
+                               r.stream[b]);
+            pend_o0[b] = o0;
+            pend_len[b] = olen;
+        }
+        if (e == hipSuccess) e = hipEventRecord(r.done[b], r.stream[b]);
     }
     for (int i = 0; i < nbuf; ++i) {
         const hipError_t e2 = hipStreamSynchronize(r.stream[i]);
         if (e == hipSuccess) e = e2;
     }
+    for (int i = 0; i < nbuf && e == hipSuccess && rc == PARRM_OK; ++i) e = drain(i);
     unpin();
     if (rc != PARRM_OK) return rc;
     if (e != hipSuccess) return parrm::hip_fail(e, "filter_host: streaming");

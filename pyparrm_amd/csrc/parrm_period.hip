@@ -366,6 +366,7 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
                 for (int rt = 0; rt < 3; ++rt)
                     acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
             }
+#ifndef PARRM_EXP_NO_GRAM
             if constexpr (NW == 4) {
                 // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
                 // compiler shuttle the Gram accumulators between register files every step)
@@ -380,6 +381,7 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
                     for (int ct = 0; ct < 3; ++ct)
                         gacc[gr][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gr], a[ct], gacc[gr][ct], 0, 0, 0);
             }
+#endif
         }
     }
     // y'y: the four sample lanes of a column hold partial sums

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of every filter_data form round 2 added, against the closed form (oracle):
+
+* resident launches with float64 and (float32 recordings) float32 output -- the packed float32 ring;
+* every kernel the plan offers (auto, gather, stride, phase, and the opt-in three-residue form);
+* channel blocks cut like a larger recording (``total_chans``), compared BITWISE with the whole launch;
+* random windows (``apply_window``) and host streaming with random chunk lengths (``apply_host``);
+* non-finite samples (NaN, +-Inf) scattered into the recording: exactly the outputs a bad sample
+  reaches are 0, every other output keeps its value -- from every kernel and every chunking.
+
+    python scripts/fuzz_filter_r2.py --cases 200 --seed 0
+    python scripts/fuzz_filter_r2.py --cases 200 --seed 0 --list          # the cases, nothing run (no GPU)
+    python scripts/fuzz_filter_r2.py --cases 200 --seed 0 --only 141 -v   # one case, a line before every launch
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+KNOBS = ("PARRM_PHASE_SHAPE", "PARRM_STRETCH_SAMPLES", "PARRM_PHASE3", "PARRM_NO_F32_PACK", "PARRM_PHASE_FORCE_WRAP")
+
+
+def draw_cases(n_cases: int, seed: int):
+    """Yield (case index, (spec, taps) or None, recording) -- every random decision of a case, drawn in one
+    fixed order, so a case can be listed or re-run alone."""
+    from oracle import parrm_oracle as orc
+
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        period = float(rng.choice([7.7424, 13.0, 64.3, 101.77, 169.2359, 169.5, 250.01, 333.3, 480.9]))
+        period *= 1 + rng.uniform(-2e-3, 2e-3)
+        n_chans = int(rng.integers(1, 9))
+        n_samples = int(rng.choice([1, 2, 17, 500, 5000, 40_000, 131_073, 300_000, 700_001, 1_200_000]))
+        hw_max = max(1, (n_samples - 1) // 2)
+        hw = int(min(hw_max, rng.choice([3, 50, 650, 2372, 6000])))
+        omit = int(rng.integers(0, max(1, min(hw, 30))))
+        direction = str(rng.choice(["both", "past", "future"]))
+        phw = float(period / rng.choice([50, 20, 8]))
+        try:
+            taps = orc.generate_filter(period, hw, omit, direction, phw)
+        except RuntimeError:
+            yield case, None, None
+            continue
+        n_taps = int(np.count_nonzero(taps)) - 1
+        while n_taps * n_chans * n_samples > 1.5e9:  # keep the closed form (NumPy, one pass per tap) to ~2 s per case
+            if n_chans > 1:
+                n_chans -= 1
+            else:
+                n_samples = n_samples // 2 + 1
+        f32 = bool(rng.random() < 0.45)
+        dtype = np.float32 if f32 else np.float64
+        x = rng.standard_normal((n_chans, n_samples)).astype(dtype)
+        poisoned = bool(rng.random() < 0.3 and n_samples >= 500)
+        bad = []
+        if poisoned:
+            for _ in range(int(rng.integers(1, 4))):
+                c, n = int(rng.integers(0, n_chans)), int(rng.integers(0, n_samples))
+                x[c, n] = rng.choice([np.nan, np.inf, -np.inf])
+                bad.append((c, n, float(x[c, n])))
+        env = {
+            "PARRM_PHASE_SHAPE": str(rng.choice(["", "", "4,2", "2,4", "2,3", "3,2", "2,2", "1,4"])),
+            "PARRM_STRETCH_SAMPLES": str(rng.choice(["", "", "20000", "60000"])),
+            "PARRM_PHASE3": "1" if rng.random() < 0.2 else "",
+            "PARRM_NO_F32_PACK": "1" if rng.random() < 0.15 else "",
+            "PARRM_PHASE_FORCE_WRAP": "1" if rng.random() < 0.15 else "",
+        }
+        spec = dict(period=period, n_chans=n_chans, n_samples=n_samples, hw=hw, omit=omit, direction=direction, phw=phw,
+                    n_taps=n_taps, dtype=dtype.__name__, bad=bad, env={k: v for k, v in env.items() if v},
+                    block=None, window=None, host=None)
+        if n_chans >= 2:
+            lo = int(rng.integers(0, n_chans - 1))
+            spec["block"] = (lo, int(rng.integers(lo + 1, n_chans + 1)))
+        if n_samples >= 17:
+            o0 = int(rng.integers(0, n_samples - 1))
+            olen = int(rng.integers(1, n_samples - o0 + 1))
+            b0 = max(0, o0 - hw - int(rng.integers(0, 40)))
+            b1 = min(n_samples, o0 + olen + hw + int(rng.integers(0, 40)))
+            spec["window"] = (o0, olen, b0, b1)
+        if n_samples >= 500 and rng.random() < 0.5:
+            chunk = int(rng.choice([0, max(1, n_samples // 7), max(1, n_samples // 3 + 1), 4096]))
+            spec["host"] = (chunk, "float32" if (f32 and rng.random() < 0.5) else "float64")
+        yield case, (spec, taps), x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--list", action="store_true", help="print every case's parameters, run nothing (needs no GPU)")
+    ap.add_argument("--only", type=int, default=-1, help="run this case only (the others are drawn and skipped)")
+    ap.add_argument("-v", "--verbose", action="store_true", help="a line before every launch, a sync after it")
+    args = ap.parse_args()
+    if args.list:
+        for case, st, _x in draw_cases(args.cases, args.seed):
+            print(case, "skipped (empty filter)" if st is None else st[0])
+        return
+    import torch
+
+    from oracle import parrm_oracle as orc
+    from pyparrm_amd import _hip
+
+    _hip.require_gpu()
+    worst = {"f64": 0.0, "f32->f64": 0.0, "f32->f32": 0.0}
+    counts = {"launches": 0, "windows": 0, "host": 0, "blocks": 0, "poisoned": 0, "skipped": 0}
+
+    def note(msg):
+        if args.verbose:
+            torch.cuda.synchronize()
+            print("   ", msg, flush=True)
+
+    def check(what, y, ref, tol, desc):
+        scale = max(float(np.abs(ref).max()), 1e-300)
+        err = float(np.abs(y.astype(np.float64) - ref).max()) / scale if y.size else 0.0
+        if not err <= tol:
+            where = np.argwhere(~(np.abs(y.astype(np.float64) - ref) <= tol * scale))
+            print(f"FAIL {what}: {desc}: rel err {err:.3e} at {where[:5].tolist()} ({where.shape[0]} outputs)")
+            sys.exit(1)
+        return err
+
+    for case, st, x in draw_cases(args.cases, args.seed):
+        if st is None:
+            counts["skipped"] += 1
+            continue
+        if args.only >= 0 and case != args.only:
+            continue
+        spec, taps = st
+        desc = f"case {case}: {spec}"
+        if args.verbose:
+            print(desc, flush=True)
+        for key in KNOBS:
+            if key in spec["env"]:
+                os.environ[key] = spec["env"][key]
+            else:
+                os.environ.pop(key, None)
+        f32 = spec["dtype"] == "float32"
+        n_chans, n_samples = spec["n_chans"], spec["n_samples"]
+        counts["poisoned"] += bool(spec["bad"])
+        plan = _hip.FilterPlan(taps)
+        ref = orc.filter_data_direct(x.astype(np.float64), taps)
+        d_x = torch.from_numpy(x).cuda()
+        kernels = [_hip.KERNEL_AUTO, _hip.KERNEL_GATHER]
+        if plan.info.stride > 0:
+            kernels.append(_hip.KERNEL_STRIDE)
+        if plan.info.phase_groups > 0:
+            kernels.append(_hip.KERNEL_PHASE)
+        outs = [torch.float64] + ([torch.float32] if f32 else [])
+        for kern in kernels:
+            plan.set_kernel(kern)
+            for out_dtype in outs:
+                key = "f64" if not f32 else ("f32->f64" if out_dtype == torch.float64 else "f32->f32")
+                tol = {"f64": 1e-10, "f32->f64": 1e-5, "f32->f32": 1e-5}[key]
+                note(f"resident kernel {kern} out {out_dtype}")
+                y = plan.apply(d_x, out_dtype=out_dtype).cpu().numpy()
+                counts["launches"] += 1
+                worst[key] = max(worst[key], check(f"resident kernel {kern} out {out_dtype}", y, ref, tol, desc))
+                if spec["bad"]:  # zeros exactly where the closed form has them
+                    z_ref, z_got = ref == 0.0, y == 0.0
+                    if not np.array_equal(z_ref, z_got):
+                        print(f"FAIL zero pattern kernel {kern} out {out_dtype}: {desc}: "
+                              f"{int((z_ref != z_got).sum())} outputs differ")
+                        sys.exit(1)
+        plan.set_kernel(_hip.KERNEL_AUTO)
+        tol = 1e-5 if f32 else 1e-10
+        # channel block of a larger recording == the same rows of the whole launch, bit for bit
+        if spec["block"]:
+            lo, hi = spec["block"]
+            note(f"channel block [{lo},{hi}) of {n_chans}")
+            whole = plan.apply(d_x, out_dtype=outs[-1])
+            block = plan.apply(d_x[lo:hi], out_dtype=outs[-1], total_chans=n_chans)
+            counts["blocks"] += 1
+            if not torch.equal(block, whole[lo:hi]):
+                print(f"FAIL channel block [{lo},{hi}) is not bit-identical to the whole launch: {desc}")
+                sys.exit(1)
+        # a random window of the outputs from a buffer that holds just what the window needs
+        if spec["window"]:
+            o0, olen, b0, b1 = spec["window"]
+            note(f"window out [{o0},{o0 + olen}) buf [{b0},{b1})")
+            buf = d_x[:, b0:b1].contiguous()
+            yw = plan.apply_window(buf, b0, o0, olen, n_samples).cpu().numpy()
+            counts["windows"] += 1
+            check(f"window out [{o0},{o0 + olen}) buf [{b0},{b1})", yw, ref[:, o0:o0 + olen], tol, desc)
+        # host streaming with a random chunk length
+        if spec["host"]:
+            chunk, out_name = spec["host"]
+            note(f"host streaming chunk {chunk} out {out_name}")
+            yh = plan.apply_host(x, out_dtype=np.dtype(out_name).type, chunk_samples=chunk)
+            counts["host"] += 1
+            check(f"host streaming chunk {chunk} out {out_name}", yh, ref, tol, desc)
+        note("case done")
+        del plan, d_x
+        if case % 10 == 9:
+            print(f"  ... {case + 1} cases, worst so far {worst}", flush=True)
+    for key in KNOBS:
+        os.environ.pop(key, None)
+    torch.cuda.synchronize()
+    print(f"{args.cases} cases ok ({counts}); worst relative error {worst}")
+
+
+if __name__ == "__main__":
+    main()

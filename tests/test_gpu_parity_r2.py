@@ -633,3 +633,77 @@ def test_channel_blocks_are_cut_like_the_whole_recording():
         for rows in (6, 16):
             parts = [plan.apply(x[lo:lo + rows].contiguous(), out_dtype=out_dtype, total_chans=48) for lo in range(0, 48, rows)]
             assert torch.equal(torch.cat(parts), whole), (dtype, rows)
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PARRM_REPO"])
+from pyparrm_amd import PARRM
+from pyparrm_amd.sharding import ShardedPARRM, TorchExchange
+from pyparrm_amd.synth import synth_recording_exact
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ex = TorchExchange(dist)
+assert ex.world_size == 1 and not ex._via_host
+t = torch.arange(12, dtype=torch.float64, device="cuda").reshape(3, 4)[:, :3]   # non-contiguous on purpose
+parts = ex.all_gather(t)
+assert len(parts) == 1 and parts[0].is_cuda and torch.equal(parts[0], t)
+
+
+x = synth_recording_exact(3, 40000, 22000 / 130 * (1 + 2e-5), seed=9)
+one = PARRM(x, 22000, 130, verbose=False)
+one.find_period(random_seed=3)
+sh = ShardedPARRM(x, 22000, 130, ex, verbose=False)
+sh.find_period(random_seed=3)
+assert sh.period == one.period
+sh.create_filter(); one.create_filter()
+assert np.array_equal(sh.filter_data(), one.filter_data())
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_torch_exchange_over_rccl_one_rank_group():
+    """The device exchange of the sharded search on the real RCCL backend (a one-rank group is all a
+    one-GPU box can host: RCCL refuses two ranks on one device)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", PARRM_REPO=os.path.dirname(HERE),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_host_streaming_staged_and_locked_in_place_agree(monkeypatch):
+    """parrm_filter_host reaches the caller's buffers three ways (already locked / locked by the call when
+    >= 64 MiB / staged through the call's own page-locked buffers): same bits from all of them."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((9, 2_000_000)).astype(np.float32)  # 72 MB: locked in place by the call
+    assert x.nbytes >= 64 << 20
+    filt = orc.generate_filter(169.2359, 2372, 0, "both", 169.2359 / 50)
+    plan = _hip.FilterPlan(filt)
+    locked = plan.apply_host(x, out_dtype=np.float32, chunk_samples=300_001)
+    monkeypatch.setenv("PARRM_HOST_NO_LOCK", "1")
+    staged = plan.apply_host(x, out_dtype=np.float32, chunk_samples=300_001)
+    monkeypatch.delenv("PARRM_HOST_NO_LOCK")
+    assert np.array_equal(locked, staged)
+    small = np.ascontiguousarray(x[:2, :150_000])  # 1.2 MB: always staged
+    got = plan.apply_host(small, out_dtype=np.float64, chunk_samples=40_000)
+    ref = orc.filter_data_direct(small.astype(np.float64), filt)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+    # a pre-locked small buffer is used in place and stays locked
+    out = np.empty_like(got)
+    _hip.pin_host(small)
+    _hip.pin_host(out)
+    try:
+        again = plan.apply_host(small, out_dtype=np.float64, chunk_samples=40_000, out=out)
+        assert again is out and np.array_equal(out, got)
+    finally:
+        _hip.unpin_host(out)
+        _hip.unpin_host(small)
