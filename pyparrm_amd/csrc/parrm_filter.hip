@@ -349,6 +349,10 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     auto *p = new parrm_filter_plan();
     p->hw = hw;
     p->n_taps = n_taps;
+    for (int64_t w = 1; w <= hw; ++w) {  // tap[w + hw] is the tap at offset w: y[n] reads x[n - w]
+        if (p->w_pos_min == 0 && tap[hw + w]) p->w_pos_min = w;
+        if (p->w_neg_min == 0 && tap[hw - w]) p->w_neg_min = w;
+    }
     std::vector<int32_t> runs;
     for (int64_t i = 0; i < filter_len;) {
         if (!tap[i]) {
@@ -507,6 +511,8 @@ int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int
     a.hw = static_cast<int32_t>(plan->hw);
     a.n_taps = static_cast<int32_t>(plan->n_taps);
     a.inv_taps = 1.0 / static_cast<double>(plan->n_taps);
+    a.w_pos_min = static_cast<int32_t>(plan->w_pos_min);
+    a.w_neg_min = static_cast<int32_t>(plan->w_neg_min);
     const int kernel = resolve_kernel(plan, total_chans, out_len);
     hipStream_t s = parrm::as_stream(stream);
     if (x_dtype == PARRM_F64) return launch<double, double>(plan, a, kernel, s);

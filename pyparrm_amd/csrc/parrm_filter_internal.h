@@ -25,6 +25,7 @@ struct FilterArgs {
     int32_t q, ring_mask, rows_per_fill;
     int64_t stretch_len, n_stretch;
     double inv_taps;
+    int32_t w_pos_min, w_neg_min;  // smallest |w| among the taps with w > 0 / w < 0 (0: the filter has none of that sign)
 };
 
 // number of taps whose source sample n-w lies inside [0, n_total)
@@ -72,15 +73,27 @@ __device__ inline void gather_output(const FilterArgs &a, int64_t c, int64_t n) 
 // so from there to the end of the stretch every output of that class is non-finite -- although only the
 // outputs whose taps reach the bad sample should be 0 (parrm.py:869) and the others have finite values.
 // The recurrence kernels therefore do NOT apply :869 themselves: they store what they computed, and this
-// pass runs behind every recurrence launch.  Because the poison survives to the end of a stretch, a
-// stretch that produced any non-finite output shows one among its last q <= 512 outputs (each residue
-// class has one there); the pass probes those outputs of every stretch (0.1 % of the output, L2-warm) and
-// recomputes a stretch that shows one tap by tap, as the gather kernel does, zeroing exactly the outputs
-// whose taps reach a non-finite sample.  Clean recordings pay the probe only (20 us at 256 ch x 10 M), the
-// hot loops lose the per-output finiteness test (three vector instructions per output), and an all-zero
-// channel (a dead electrode) is not mistaken for a poisoned one.  A flag kept in the phase kernel instead
-// cost it a VGPR -- one wave per SIMD at its 80-register budget (9.5 -> 10.8 ms).  Result: every kernel
-// variant and every chunking returns what the direct evaluation returns, on the poisoned channel too.
+// pass runs behind every recurrence launch.
+//   (1) Because the poison survives to the end of a stretch, a stretch in which a bad sample was a TAP of
+//       any output shows a non-finite value among its last q <= 512 outputs (each residue class has one
+//       there); the pass probes those outputs of every stretch (0.1 % of the output, L2-warm) and
+//       recomputes a stretch that shows one tap by tap, as the gather kernel does, zeroing exactly the
+//       outputs whose taps reach a non-finite sample.
+//   (2) A bad sample x[p] that is a tap of NO output of its stretch spoils exactly one output there, its
+//       own (y[p] = x[p] - mean), and leaves no trace at the tail.  x[p] is a tap of the outputs p + w, so it
+//       is a tap of none in [o0, o1) iff p + w_pos_min >= o1 (or the filter has no tap with w > 0) AND
+//       p - w_neg_min < o0 (or no tap with w < 0): for a two-sided filter nowhere (unless the stretch is
+//       shorter than w_pos_min + w_neg_min), for a one-sided one the first or last few samples of every
+//       stretch -- a "past" filter never reads x[p] for an output at or behind p.  The pass reads the input
+//       over that interval and stores 0 wherever the sample itself is non-finite, which is what :869 makes
+//       of such an output whatever its taps hold.  (Found by scripts/fuzz_filter_r2.py, case 182.  Testing
+//       every loaded sample inside the phase kernel instead cost it 2 % (float64) to 4.5 % (float32): one
+//       more vector instruction per output at its issue limit.)
+// Clean recordings pay the probe (and, with a one-sided filter, that short read) only, the hot loops lose the per-output finiteness
+// test (three vector instructions per output), and an all-zero channel (a dead electrode) is not mistaken
+// for a poisoned one.  A flag kept in the phase kernel cost it a VGPR -- one wave per SIMD at its
+// 80-register budget (9.5 -> 10.8 ms).  Result: every kernel variant and every chunking returns what the
+// direct evaluation returns, on the poisoned channel too.
 constexpr int kRepairStretchesPerBlock = 4;
 constexpr int kRepairProbe = 512;
 
@@ -88,7 +101,7 @@ template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) filter_repair_kernel(FilterArgs a) {
     const int64_t n_str = a.n_chans * a.n_stretch;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kRepairStretchesPerBlock;
-    const TO *y = static_cast<const TO *>(a.y);
+    TO *y = static_cast<TO *>(a.y);
     for (int64_t s = first; s < first + kRepairStretchesPerBlock && s < n_str; ++s) {
         const int64_t c = s / a.n_stretch, st = s - c * a.n_stretch;
         const int64_t o0 = st * a.stretch_len;
@@ -97,8 +110,16 @@ __global__ void __launch_bounds__(256) filter_repair_kernel(FilterArgs a) {
         int hit = 0;
         for (int64_t i = p0 + threadIdx.x; i < o1; i += blockDim.x)
             if (!isfinite(static_cast<double>(y[c * a.ldy + i]))) hit = 1;
-        if (!__syncthreads_or(hit)) continue;  // workgroup-uniform
-        for (int64_t i = o0 + threadIdx.x; i < o1; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
+        if (__syncthreads_or(hit)) {  // workgroup-uniform
+            for (int64_t i = o0 + threadIdx.x; i < o1; i += blockDim.x) gather_output<TI, TO>(a, c, a.out_first + i);
+            continue;
+        }
+        // (2): samples of this stretch that are taps of none of its outputs
+        const int64_t lo = a.w_pos_min > 0 && o1 - a.w_pos_min > o0 ? o1 - a.w_pos_min : o0;
+        const int64_t hi = a.w_neg_min > 0 && o0 + a.w_neg_min < o1 ? o0 + a.w_neg_min : o1;
+        const TI *row = static_cast<const TI *>(a.x) + c * a.ldx - a.buf_first + a.out_first;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+            if (!isfinite(static_cast<double>(row[i]))) y[c * a.ldy + i] = TO(0);
     }
 }
 
@@ -158,6 +179,7 @@ int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, h
 struct parrm_filter_plan {
     int device = 0;
     int64_t hw = 0, n_taps = 0, n_runs = 0;
+    int64_t w_pos_min = 0, w_neg_min = 0;  // nearest tap behind / ahead of the centre (0: none on that side)
     int64_t q = 0, n_delta = 0, n_delta_pad = 0;
     int ring_log2_f64 = 0, rows_per_fill = 0, block_threads = 0;
     int forced_kernel = PARRM_KERNEL_AUTO;

@@ -707,3 +707,41 @@ def test_host_streaming_staged_and_locked_in_place_agree(monkeypatch):
     finally:
         _hip.unpin_host(out)
         _hip.unpin_host(small)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direction", ["past", "future", "both"])
+@pytest.mark.parametrize("dtype,out_dtype", [(np.float64, "float64"), (np.float32, "float32")])
+def test_nonfinite_sample_that_is_a_tap_of_no_output_in_its_stretch(monkeypatch, direction, dtype, out_dtype):
+    """A one-sided filter never reads x[p] for the outputs on one side of p: a NaN/Inf that sits next to a
+    stretch seam (or the recording's end) then spoils only its own output there and never enters a running
+    sum of that stretch (scripts/fuzz_filter_r2.py, seed 0 case 182).  Every kernel must still return the
+    closed form: 0 at that output, and at every output whose taps reach the sample."""
+    monkeypatch.setenv("PARRM_STRETCH_SAMPLES", "20000")  # seams every ~20 K samples (whole rows of the stride)
+    period, hw = 333.94747991470695, 2372
+    filt = orc.generate_filter(period, hw, 15, direction, period / 50)
+    n = 150_000
+    x = np.random.default_rng(5).standard_normal((3, n)).astype(dtype)
+    plan = _hip.FilterPlan(filt)
+    info = plan.info
+    q = int(info.phase_stride or info.stride)
+    assert q > 0
+    # a bad sample on each side of several seams, whatever row count the launch settles on
+    for k, p in enumerate(range(19_000, 21_500, 111)):
+        x[k % 2, p] = [np.inf, -np.inf, np.nan][k % 3]
+    x[2, 0] = np.inf
+    x[2, n - 1] = -np.inf
+    ref = orc.filter_data_direct(x.astype(np.float64), filt)
+    d_x = torch.from_numpy(x).cuda()
+    kernels = [_hip.KERNEL_AUTO, _hip.KERNEL_GATHER]
+    if info.stride > 0:
+        kernels.append(_hip.KERNEL_STRIDE)
+    if info.phase_groups > 0:
+        kernels.append(_hip.KERNEL_PHASE)
+    tol = 1e-10 if dtype == np.float64 else 1e-5
+    for kern in kernels:
+        plan.set_kernel(kern)
+        y = plan.apply(d_x, out_dtype=getattr(torch, out_dtype)).cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(y)), kern
+        assert np.array_equal(y == 0, ref == 0), kern
+        assert np.abs(y - ref).max() <= tol * np.abs(ref).max(), kern
