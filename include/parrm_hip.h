@@ -45,6 +45,8 @@ extern "C" {
 #define PARRM_KERNEL_GATHER 1 /* one thread per output, taps gathered from global/L2        */
 #define PARRM_KERNEL_STRIDE 2 /* LDS ring + stride-q running-sum recurrence (any tap pattern) */
 #define PARRM_KERNEL_PHASE 3  /* phase-major LDS ring, R rows per thread (comb filters, T>=64) */
+#define PARRM_KERNEL_SEGMENTED 4 /* reported only: half-width beyond any LDS ring -- the taps are cut into
+                                    offset windows, one phase-kernel pass each, summed in float64 */
 
 int parrm_hip_abi_version(void);
 const char *parrm_hip_last_error(void);

@@ -248,7 +248,47 @@ int resolve_kernel(const parrm_filter_plan *p, int64_t n_chans, int64_t out_len)
     // tiny problems: the per-stretch prologue (2*hw + ... samples) would dominate
     if (n_chans * out_len < (int64_t{1} << 15)) return PARRM_KERNEL_GATHER;
     if (has_phase) return PARRM_KERNEL_PHASE;
-    return has_stride ? PARRM_KERNEL_STRIDE : PARRM_KERNEL_GATHER;
+    if (has_stride) return PARRM_KERNEL_STRIDE;
+    return p->segments.empty() ? PARRM_KERNEL_GATHER : PARRM_KERNEL_SEGMENTED;
+}
+
+void fill_plan_args(const parrm_filter_plan *plan, FilterArgs *a) {
+    a->runs = plan->d_tables;
+    a->tapcum = plan->d_tables + plan->off_tapcum;
+    a->delta = plan->d_tables + plan->off_delta;
+    a->n_runs = static_cast<int32_t>(plan->n_runs);
+    a->delta_w = plan->d_weights;
+    a->hw = static_cast<int32_t>(plan->hw);
+    a->n_taps = static_cast<int32_t>(plan->n_taps);
+    a->inv_taps = 1.0 / static_cast<double>(plan->n_taps);
+    a->w_pos_min = static_cast<int32_t>(plan->w_pos_min);
+    a->w_neg_min = static_cast<int32_t>(plan->w_neg_min);
+}
+
+// Last step of a segmented launch: acc holds the zero-padded tap sum of the WHOLE filter for every output;
+// y = x - acc / (taps inside the recording), parrm.py:861-869.  A non-finite result is recomputed tap by tap
+// (gather_output): the passes' running sums carry a NaN/Inf to the end of their stretches, far beyond the
+// outputs whose taps reach the bad sample, and the direct evaluation zeroes exactly those.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) filter_combine_kernel(FilterArgs a, const double *acc, int64_t ldacc) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= a.out_len) return;
+    const int64_t n = a.out_first + i;
+    for (int64_t c = blockIdx.y; c < a.n_chans; c += gridDim.y) {
+        const double xc = static_cast<double>(static_cast<const TI *>(a.x)[c * a.ldx + (n - a.buf_first)]);
+        const double s = acc[c * ldacc + i];
+        double y;
+        if (n >= a.hw && n + a.hw < a.n_total) {
+            y = xc - s * a.inv_taps;
+        } else {
+            const int v = valid_taps(a, n);
+            y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
+        }
+        if (isfinite(y))
+            static_cast<TO *>(a.y)[c * a.ldy + i] = static_cast<TO>(y);
+        else
+            gather_output<TI, TO>(a, c, n);
+    }
 }
 
 template <typename TI, typename TO>
@@ -256,7 +296,55 @@ int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStr
 
 // A recurrence launch is followed by the repair pass (parrm_filter_internal.h: non-finite inputs).
 template <typename TI, typename TO>
+int launch_segmented(const parrm_filter_plan *p, FilterArgs a, hipStream_t stream) {
+    // the float64 accumulator: the output itself when that is float64, a stream-ordered scratch otherwise
+    double *acc = nullptr;
+    int64_t ldacc = a.out_len;
+    void *scratch = nullptr;
+    if constexpr (sizeof(TO) == 8) {
+        acc = static_cast<double *>(a.y);
+        ldacc = a.ldy;
+    } else {
+        PARRM_HIP_CHECK(hipMallocAsync(&scratch, static_cast<size_t>(a.n_chans * a.out_len) * sizeof(double), stream));
+        acc = static_cast<double *>(scratch);
+    }
+    int rc = PARRM_OK;
+    hipError_t e = hipSuccess;  // (the first pass stores, the others add: no clear)
+    for (size_t k = 0; k < p->segments.size() && e == hipSuccess && rc == PARRM_OK; ++k) {
+        // window [c - H, c + H] of the taps = the sub-plan's filter applied to the recording shifted by c.  In the
+        // frame of a recording of N + 2|c| samples that holds the data at [|c|, |c| + N) (the rest is not
+        // addressable, i.e. reads as zero) every index is non-negative: output n sits at n - c + |c|.
+        const parrm_filter_plan *sub = p->segments[k];
+        const int64_t c = p->seg_centre[k], shift = c < 0 ? -c : c;
+        FilterArgs b = a;
+        fill_plan_args(sub, &b);
+        b.y = acc;
+        b.ldy = ldacc;
+        b.buf_first = a.buf_first + shift;
+        b.n_total = a.n_total + 2 * shift;
+        b.out_first = a.out_first - c + shift;
+        rc = launch_phase<TI, double>(sub, &b, stream, k == 0 ? 2 : 1);
+    }
+    if (e == hipSuccess && rc == PARRM_OK) {
+        const int block = 256;
+        const int64_t gx = (a.out_len + block - 1) / block;
+        const int64_t gy = std::min<int64_t>(a.n_chans, 65535);
+        hipLaunchKernelGGL((filter_combine_kernel<TI, TO>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)),
+                           dim3(block), 0, stream, a, acc, ldacc);
+        e = hipGetLastError();
+    }
+    if (scratch) {
+        const hipError_t e2 = hipFreeAsync(scratch, stream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (rc != PARRM_OK) return rc;
+    if (e != hipSuccess) return parrm::hip_fail(e, "filter: segmented launch");
+    return PARRM_OK;
+}
+
+template <typename TI, typename TO>
 int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
+    if (kernel == PARRM_KERNEL_SEGMENTED) return launch_segmented<TI, TO>(p, a, stream);
     const int rc = launch_main<TI, TO>(p, &a, kernel, stream);
     if (rc != PARRM_OK || kernel == PARRM_KERNEL_GATHER || getenv("PARRM_NO_REPAIR_PASS")) return rc;
     const int64_t blocks = (a.n_chans * a.n_stretch + kRepairStretchesPerBlock - 1) / kRepairStretchesPerBlock;
@@ -323,6 +411,10 @@ int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStr
 
 extern "C" {
 
+// Plan for a tap mask (tap[w + hw] = 1 for a tap at offset w; the centre may be one: segments of a long
+// filter are masks of their own).  `allow_segments`: cut a filter that has no fast kernel into offset windows.
+static int build_plan(const std::vector<int8_t> &tap, int64_t hw, bool allow_segments, parrm_filter_plan **plan);
+
 int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_filter_plan **plan) {
     PARRM_REQUIRE(h_filter && plan, "filter_plan_create: NULL argument");
     PARRM_REQUIRE(filter_len >= 3 && (filter_len & 1), "filter_plan_create: filter length must be odd and >= 3");
@@ -334,14 +426,96 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     }
     const int64_t hw = (filter_len - 1) / 2;
     std::vector<int8_t> tap(filter_len, 0);
-    int64_t n_taps = 0;
     for (int64_t i = 0; i < filter_len; ++i) {
         if (i == hw) continue;  // the centre carries the 1 (parrm.py:831)
-        if (h_filter[i] != 0.0) {
-            tap[i] = 1;
-            ++n_taps;
+        if (h_filter[i] != 0.0) tap[i] = 1;
+    }
+    return build_plan(tap, hw, true, plan);
+}
+
+// Segmented plans.  A half-width the LDS cannot hold (2 hw + 3 q samples for the stride kernel, (2 hw / q + NG R)
+// rows of q samples for the phase kernel) used to fall to the gather kernel: every output re-reads all its S taps
+// from L2 -- 22 ms for 64 ch x 1 M at hw = 9 000 (722 taps), 134 ms at hw = 60 000.  The tap sum is additive over
+// any partition of the taps, and a window [c - H, c + H] of offsets is a filter of half-width H applied to the
+// recording shifted by c.  So the taps are cut into K windows that each HAVE a phase plan, each window's raw
+// zero-padded tap sum is added into a float64 accumulator by one phase-kernel pass (MODE 1), and one light kernel
+// turns the accumulator into outputs (own sample, divisor from the whole filter's cumulative tap counts).
+// Traffic: 16 B (first pass: stores) + (K - 1) x 24 B + 24 B per sample instead of S x 8 B from L2.
+static void build_segments(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p) {
+    double best_cost = 1e300;
+    std::vector<parrm_filter_plan *> best;
+    std::vector<int64_t> best_centre;
+    auto release = [](std::vector<parrm_filter_plan *> &v) {
+        for (parrm_filter_plan *q : v) (void)parrm_filter_plan_destroy(q);
+        v.clear();
+    };
+    // Measured (64 ch x 1 M float64, scripts/sweep_segments.py): a pass costs ~0.36 ms + 0.055 ms per 1000 samples
+    // of window half-width (the accumulator's 16 B per sample and the per-stretch prologues dominate), so few wide
+    // windows win until the ring stops fitting (H ~ 8000 at q = 169).  Candidates: K equal windows for the few
+    // smallest K whose windows can have phase plans.
+    const char *force = getenv("PARRM_SEGMENT_HALFWIDTH");  // tuning knob: this window half-width only
+    std::vector<int64_t> candidates;
+    if (force) {
+        candidates.push_back(atoll(force));
+    } else {
+        const int64_t span_all = 2 * hw + 1;
+        for (int64_t k = 2; k <= 4096; k = std::max<int64_t>(k + 1, k * 9 / 8)) {
+            const int64_t H = ((span_all + k - 1) / k) / 2 + 1;
+            if (H > 9000) continue;
+            if (H < 300) break;
+            if (candidates.empty() || candidates.back() != H) candidates.push_back(H);
         }
     }
+    int tried_ok = 0;
+    for (const int64_t H : candidates) {
+        if (H >= hw || H < 1) continue;
+        if (tried_ok >= 3) break;  // costs only grow with more, narrower windows
+        const int64_t width = 2 * H + 1, span = 2 * hw + 1;
+        const int64_t k_windows = (span + width - 1) / width;
+        std::vector<parrm_filter_plan *> subs;
+        std::vector<int64_t> centres;
+        double cost = 0.0;
+        bool ok = true;
+        for (int64_t k = 0; k < k_windows && ok; ++k) {
+            const int64_t lo = -hw + k * width;                      // offsets [lo, lo + width)
+            const int64_t c = lo + H;
+            std::vector<int8_t> mask(width, 0);
+            int64_t n = 0;
+            for (int64_t j = 0; j < width; ++j) {
+                const int64_t w = lo + j;
+                if (w <= hw && tap[w + hw]) {
+                    mask[j] = 1;
+                    ++n;
+                }
+            }
+            if (n == 0) continue;
+            parrm_filter_plan *sub = nullptr;
+            if (build_plan(mask, H, false, &sub) != PARRM_OK || sub->phase.n_groups == 0) {
+                if (sub) (void)parrm_filter_plan_destroy(sub);
+                ok = false;
+                break;
+            }
+            subs.push_back(sub);
+            centres.push_back(c);
+            cost += 0.36 + 0.055 * static_cast<double>(H) / 1000.0;
+        }
+        if (ok && !subs.empty()) ++tried_ok;
+        if (ok && !subs.empty() && cost < best_cost) {
+            release(best);
+            best_cost = cost;
+            best.swap(subs);
+            best_centre.swap(centres);
+        }
+        release(subs);
+    }
+    p->segments.swap(best);
+    p->seg_centre.swap(best_centre);
+}
+
+static int build_plan(const std::vector<int8_t> &tap, int64_t hw, bool allow_segments, parrm_filter_plan **plan) {
+    const int64_t filter_len = 2 * hw + 1;
+    int64_t n_taps = 0;
+    for (int64_t i = 0; i < filter_len; ++i) n_taps += tap[i];
     if (n_taps == 0) {
         parrm::set_error("filter_plan_create: the filter has no taps");
         return PARRM_ERR_EMPTY_FILTER;
@@ -406,6 +580,7 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
     p->d_tables = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb);
     p->d_phase_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb);
     p->d_phase3_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb + pb);
+    if (allow_segments && p->phase.n_groups == 0 && p->q == 0) build_segments(tap, hw, p);
     *plan = p;
     return PARRM_OK;
 }
@@ -413,6 +588,7 @@ int parrm_filter_plan_create(const double *h_filter, int64_t filter_len, parrm_f
 int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
     if (!plan) return PARRM_OK;
     if (plan->d_weights) (void)hipFree(plan->d_weights);  // the one allocation (weights | tables | phase table)
+    for (parrm_filter_plan *sub : plan->segments) (void)parrm_filter_plan_destroy(sub);
     delete plan;
     return PARRM_OK;
 }
@@ -435,6 +611,7 @@ int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_inf
     info->phase_rows = plan->phase.rows;
     info->phase_row_slots = plan->phase.m_slots;
     info->phase_residues = 1;
+    info->reserved = static_cast<int32_t>(plan->segments.size());  // passes of a segmented plan (0: not segmented)
     if (plan->phase3.n_groups > 0) {  // what a PHASE launch actually runs
         info->phase_delta = 2 * plan->phase3.n_pairs;
         info->phase_groups = plan->phase3.n_groups;
@@ -503,16 +680,7 @@ int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int
     a.n_total = n_total;
     a.ldx = ldx;
     a.ldy = ldy;
-    a.runs = plan->d_tables;
-    a.tapcum = plan->d_tables + plan->off_tapcum;
-    a.delta = plan->d_tables + plan->off_delta;
-    a.n_runs = static_cast<int32_t>(plan->n_runs);
-    a.delta_w = plan->d_weights;
-    a.hw = static_cast<int32_t>(plan->hw);
-    a.n_taps = static_cast<int32_t>(plan->n_taps);
-    a.inv_taps = 1.0 / static_cast<double>(plan->n_taps);
-    a.w_pos_min = static_cast<int32_t>(plan->w_pos_min);
-    a.w_neg_min = static_cast<int32_t>(plan->w_neg_min);
+    fill_plan_args(plan, &a);
     const int kernel = resolve_kernel(plan, total_chans, out_len);
     hipStream_t s = parrm::as_stream(stream);
     if (x_dtype == PARRM_F64) return launch<double, double>(plan, a, kernel, s);

@@ -195,6 +195,11 @@ struct parrm_filter_plan {
     // three-residues-per-lane form of the phase kernel (n_groups == 0: not available for this filter)
     parrm_filter::Phase3Geom phase3{};
     int32_t *d_phase3_tab = nullptr;
+    // Segmented form (half-widths beyond any LDS ring; parrm_filter.hip): the taps cut into windows of
+    // offsets, each a plan of its own whose phase kernel adds its raw tap sums into a float64 accumulator.
+    // seg_centre[k] is the offset w the k-th sub-plan's centre stands for.  Empty: not segmented.
+    std::vector<parrm_filter_plan *> segments;
+    std::vector<int64_t> seg_centre;
 };
 
 
@@ -202,8 +207,9 @@ namespace parrm_filter {
 // parrm_filter_phase.hip
 void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *plan, std::vector<int32_t> *table);
 // (fills a->stretch_len / a->n_stretch: the repair pass needs the stretch geometry of the launch)
+// mode 0: y = x - mean of taps; TO = double only: mode 1: y += raw tap sum (a segment of a long filter), mode 2: y = it
 template <typename TI, typename TO>
-int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream);
+int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream, int mode = 0);
 // parrm_filter_phase3.hip
 bool plan_phase3(const std::vector<int8_t> &tap, int64_t hw, const PhaseGeom &phase, Phase3Geom *out,
                  std::vector<int32_t> *table);

@@ -147,9 +147,16 @@ __device__ inline void tap_pair(unsigned ad_p, unsigned ad_m, TI (&v)[4]) {
 // build option of BASELINE configs[4]): the 14 + 14 tap values of a row are summed in float32
 // (v_pk_add_f32: both rows per instruction); the running sum S and everything downstream stay float64.
 // The reference's own float32 path is an FFT in float32 (~1e-6 of the sample scale); this keeps ~4e-7.
-template <typename TI, typename TO, int DP, int R, bool WRAP, int PACK = 0>
+// MODE 1 (segmented plans, parrm_filter.hip: half-widths beyond any LDS ring; PhaseGeom::debug bit 5: store
+// instead of add, the first pass of a call): the launch evaluates one
+// SEGMENT of a long filter's taps and ADDS the raw zero-padded tap sum S(n) into the float64 accumulator
+// y[n] (global_atomic_add_f64 without return: no read latency in the loop; the passes of one call follow
+// each other on the stream and every output is touched once per pass, so the result is deterministic).  No
+// division, no own sample, no edge divisors: the caller's combine kernel applies those for the whole filter.
+template <typename TI, typename TO, int DP, int R, bool WRAP, int PACK = 0, int MODE = 0>
 __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseGeom p) {
     static_assert(PACK == 0 || (sizeof(TI) == 4 && R == 2 && !WRAP), "PACK: float32 input, two rows, guarded form");
+    static_assert(MODE == 0 || (sizeof(TO) == 8 && PACK != 2), "MODE 1 accumulates float64 sums");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int kEl = static_cast<int>(sizeof(TI));
     constexpr int kElLog2 = kEl == 8 ? 3 : 2;
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         TI xo[R];
         double delta[R];
         tap_sums(delta, (p.debug & 1) != 0);
-        own_samples(xo);
+        if constexpr (MODE == 0) own_samples(xo);
         double tot = 0.0;
 #pragma unroll
         for (int i = 0; i < R; ++i) tot += delta[i];
@@ -521,7 +528,22 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         double s_row = chain_math(tg);
         // 5. outputs.  Rows that are interior to the recording and to the stretch take a branch-free
         // path (the test is wave-uniform); edge rows go through emit().
-        if (!(p.debug & 2)) {
+        if constexpr (MODE == 1) {
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int rel = (m + i) * q + r;
+                    if (rel < len) {
+                        double *cell = reinterpret_cast<double *>(yrow) + (s0 + rel);
+                        if (p.debug & 32)
+                            *cell = s_row;  // first pass of a call
+                        else
+                            __builtin_amdgcn_global_atomic_fadd_f64(cell, s_row);
+                    }
+                    s_row += delta[i];
+                }
+            }
+        } else if (!(p.debug & 2)) {
             if (m >= erow_lo && m + R - 1 <= erow_hi) {
                 if (active) {
                     TO *yout = yrow + (s0 + static_cast<int64_t>(m) * q);
@@ -580,7 +602,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         TI xo[R];
         double delta[R];
         tap_sums(delta, false);
-        own_samples(xo);
+        if constexpr (MODE == 0) own_samples(xo);
         double tot = 0.0;
 #pragma unroll
         for (int i = 0; i < R; ++i) tot += delta[i];
@@ -612,16 +634,30 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
         fetch_table(next_top());  // next iteration's tap offsets: one wait covers them and the cells
         double s_row = chain_math(tg);
         // 5. outputs
+        if constexpr (MODE == 1) {
+            if (active) {
+                double *acc = reinterpret_cast<double *>(yrow + a.out_first) + (soff_y >> 3) + r;
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));  // (:869 is the repair pass's)
-            const TO yo = static_cast<TO>(yv);
-            if constexpr (sizeof(TO) == 8) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+                for (int i = 0; i < R; ++i) {
+                    if (p.debug & 32)
+                        acc[static_cast<int64_t>(i) * q] = s_row;  // first pass of a call
+                    else
+                        __builtin_amdgcn_global_atomic_fadd_f64(acc + static_cast<int64_t>(i) * q, s_row);
+                    s_row += delta[i];
+                }
             }
-            s_row += delta[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const double yv = fma(-s_row, a.inv_taps, static_cast<double>(xo[i]));  // (:869 is the repair pass's)
+                const TO yo = static_cast<TO>(yv);
+                if constexpr (sizeof(TO) == 8) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), rsrc_y, voff_y, soff_y + i * qy, 0);
+                }
+                s_row += delta[i];
+            }
         }
         soff_y += static_cast<unsigned>(NGR) * qy;
         advance_slots();
@@ -895,22 +931,36 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
 }
 #endif  // PARRM_PHASE_WITH_PLAN
 
+template <typename TI, typename TO, int DP, int MODE>
+static void (*pick_phase_kernel(bool packed, int rows, bool wrap))(FilterArgs, PhaseGeom) {
+    switch (packed ? 0 : rows * 2 + (wrap ? 1 : 0)) {
+        case 0:
+            if constexpr (sizeof(TI) == 4) return filter_phase_kernel<TI, TO, DP, 2, false, sizeof(TO) == 4 ? 2 : 1, MODE>;
+            break;
+        case 4: return filter_phase_kernel<TI, TO, DP, 2, false, 0, MODE>;
+        case 5: return filter_phase_kernel<TI, TO, DP, 2, true, 0, MODE>;
+        case 6: return filter_phase_kernel<TI, TO, DP, 3, false, 0, MODE>;
+        case 7: return filter_phase_kernel<TI, TO, DP, 3, true, 0, MODE>;
+        case 8: return filter_phase_kernel<TI, TO, DP, 4, false, 0, MODE>;
+        case 9: return filter_phase_kernel<TI, TO, DP, 4, true, 0, MODE>;
+        default: break;
+    }
+    return nullptr;
+}
+
 template <typename TI, typename TO, int DP>
-static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, PhaseGeom g, hipStream_t stream) {
+static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, PhaseGeom g, hipStream_t stream, int mode) {
     FilterArgs &a = *args;
     void (*kern)(FilterArgs, PhaseGeom) = nullptr;
     const bool packed = g.copy_o_bytes > 0;  // float32 recordings: the packed geometry (launch_phase chose it)
-    switch (packed ? 0 : g.rows * 2 + (g.wrap ? 1 : 0)) {
-        case 0:
-            if constexpr (sizeof(TI) == 4) kern = filter_phase_kernel<TI, TO, DP, 2, false, sizeof(TO) == 4 ? 2 : 1>;
-            break;
-        case 4: kern = filter_phase_kernel<TI, TO, DP, 2, false>; break;
-        case 5: kern = filter_phase_kernel<TI, TO, DP, 2, true>; break;
-        case 6: kern = filter_phase_kernel<TI, TO, DP, 3, false>; break;
-        case 7: kern = filter_phase_kernel<TI, TO, DP, 3, true>; break;
-        case 8: kern = filter_phase_kernel<TI, TO, DP, 4, false>; break;
-        case 9: kern = filter_phase_kernel<TI, TO, DP, 4, true>; break;
-        default: parrm::set_error("filter: unsupported rows-per-thread %d", g.rows); return PARRM_ERR_INVALID;
+    if (mode == 1) {
+        if constexpr (sizeof(TO) == 8) kern = pick_phase_kernel<TI, TO, DP, 1>(packed, g.rows, g.wrap != 0);
+    } else {
+        kern = pick_phase_kernel<TI, TO, DP, 0>(packed, g.rows, g.wrap != 0);
+    }
+    if (!kern) {
+        parrm::set_error("filter: unsupported phase kernel shape (rows %d, mode %d)", g.rows, mode);
+        return PARRM_ERR_INVALID;
     }
     const int ngr = g.n_groups * g.rows;
     // Stretch length.  A stretch costs its samples plus a fixed prologue (the ring fill of 2*hw + NG*R*q
@@ -962,7 +1012,7 @@ static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, Phase
 }
 
 template <typename TI, typename TO>
-int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream) {
+int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream, int mode) {
     PhaseGeom g = plan->phase;
     g.tab = plan->d_phase_tab;
     g.copy_o_bytes = 0;
@@ -975,20 +1025,24 @@ int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t strea
             g.tab = plan->d_phase_tab + g.tab_off;
         }
     }
-    if (const char *env = getenv("PARRM_DEBUG_FLAGS")) g.debug = atoi(env);  // profiling ablations only
+    if (const char *env = getenv("PARRM_DEBUG_FLAGS")) g.debug = atoi(env) & 31;  // profiling ablations only
+    if (mode == 2) {  // MODE 1 kernels, storing instead of adding
+        g.debug |= 32;
+        mode = 1;
+    }
     switch (g.d_pad) {
-        case 4: return launch_phase_r<TI, TO, 4>(plan, a, g, stream);
-        case 8: return launch_phase_r<TI, TO, 8>(plan, a, g, stream);
-        case 12: return launch_phase_r<TI, TO, 12>(plan, a, g, stream);
-        case 14: return launch_phase_r<TI, TO, 14>(plan, a, g, stream);
-        case 20: return launch_phase_r<TI, TO, 20>(plan, a, g, stream);
-        case 16: return launch_phase_r<TI, TO, 16>(plan, a, g, stream);
-        case 24: return launch_phase_r<TI, TO, 24>(plan, a, g, stream);
-        case 32: return launch_phase_r<TI, TO, 32>(plan, a, g, stream);
+        case 4: return launch_phase_r<TI, TO, 4>(plan, a, g, stream, mode);
+        case 8: return launch_phase_r<TI, TO, 8>(plan, a, g, stream, mode);
+        case 12: return launch_phase_r<TI, TO, 12>(plan, a, g, stream, mode);
+        case 14: return launch_phase_r<TI, TO, 14>(plan, a, g, stream, mode);
+        case 20: return launch_phase_r<TI, TO, 20>(plan, a, g, stream, mode);
+        case 16: return launch_phase_r<TI, TO, 16>(plan, a, g, stream, mode);
+        case 24: return launch_phase_r<TI, TO, 24>(plan, a, g, stream, mode);
+        case 32: return launch_phase_r<TI, TO, 32>(plan, a, g, stream, mode);
         default: parrm::set_error("filter: no phase kernel for %d delta taps per sign", g.d_pad); return PARRM_ERR_INVALID;
     }
 }
 
-template int launch_phase<PARRM_PHASE_TI, PARRM_PHASE_TO>(const parrm_filter_plan *, FilterArgs *, hipStream_t);
+template int launch_phase<PARRM_PHASE_TI, PARRM_PHASE_TO>(const parrm_filter_plan *, FilterArgs *, hipStream_t, int);
 
 }  // namespace parrm_filter

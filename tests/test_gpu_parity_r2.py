@@ -745,3 +745,51 @@ def test_nonfinite_sample_that_is_a_tap_of_no_output_in_its_stretch(monkeypatch,
         assert np.all(np.isfinite(y)), kern
         assert np.array_equal(y == 0, ref == 0), kern
         assert np.abs(y - ref).max() <= tol * np.abs(ref).max(), kern
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period,hw,direction", [(169.23584580707903, 9000, "both"), (169.23584580707903, 20000, "past"),
+                                                 (64.3, 30011, "both"), (333.3, 40000, "future")])
+def test_segmented_plan_for_half_widths_beyond_the_ring(period, hw, direction):
+    """Half-widths no LDS ring holds: the taps are cut into offset windows, one phase-kernel pass each adds its raw
+    tap sums into a float64 accumulator, a last kernel forms the outputs (PARRM_KERNEL_SEGMENTED).  Same answer
+    as the closed form for every dtype pair, for a window, for host streaming, and with NaN/Inf samples."""
+    filt = orc.generate_filter(period, hw, 3, direction, period / 40)
+    plan = _hip.FilterPlan(filt)
+    info = plan.info
+    assert int(info.kernel) == 4 and int(info.reserved) >= 2, (int(info.kernel), int(info.reserved))
+    n = 200_000
+    x = np.random.default_rng(3).standard_normal((3, n))
+    ref = orc.filter_data_direct(x, filt)
+    scale = np.abs(ref).max()
+    d_x = torch.from_numpy(x).cuda()
+    y = plan.apply(d_x).cpu().numpy()
+    assert np.abs(y - ref).max() <= 1e-10 * scale
+    plan.set_kernel(_hip.KERNEL_GATHER)
+    assert np.abs(plan.apply(d_x).cpu().numpy() - ref).max() <= 1e-10 * scale
+    plan.set_kernel(_hip.KERNEL_AUTO)
+    # float32 in, both output types
+    x32 = x.astype(np.float32)
+    ref32 = orc.filter_data_direct(x32.astype(np.float64), filt)
+    d32 = torch.from_numpy(x32).cuda()
+    assert np.abs(plan.apply(d32).cpu().numpy() - ref32).max() <= 1e-10 * scale
+    y32 = plan.apply(d32, out_dtype=torch.float32)
+    assert y32.dtype == torch.float32
+    assert np.abs(y32.cpu().numpy().astype(np.float64) - ref32).max() <= 2e-7 * scale
+    # a window and the host-streamed form
+    o0, olen = 61_234, 70_001
+    b0, b1 = max(0, o0 - hw), min(n, o0 + olen + hw)
+    yw = plan.apply_window(d_x[:, b0:b1].contiguous(), b0, o0, olen, n).cpu().numpy()
+    assert np.abs(yw - ref[:, o0:o0 + olen]).max() <= 1e-10 * scale
+    yh = plan.apply_host(x, chunk_samples=66_667)
+    assert np.abs(yh - ref).max() <= 1e-10 * scale
+    # non-finite samples: zeros exactly where the closed form has them
+    xb = x.copy()
+    xb[0, 100_000] = np.nan
+    xb[1, 5] = np.inf
+    xb[2, n - 1] = -np.inf
+    refb = orc.filter_data_direct(xb, filt)
+    yb = plan.apply(torch.from_numpy(xb).cuda()).cpu().numpy()
+    assert np.all(np.isfinite(yb))
+    assert np.array_equal(yb == 0, refb == 0)
+    assert np.abs(yb - refb).max() <= 1e-10 * scale
