@@ -339,7 +339,7 @@ def main():
                            "row_groups": int(info.phase_groups), "rows_per_thread": int(info.phase_rows)},
             },
             "roofline": {
-                "kernel": {1: "filter_gather_kernel", 2: "filter_stride_kernel", 3: "filter_phase_kernel"}[int(info.kernel)] + "<double,double>",
+                "kernel": {1: "filter_gather_kernel", 2: "filter_stride_kernel", 3: "filter_phase_kernel", 4: "filter_phase_kernel (segmented plan)"}[int(info.kernel)] + "<double,double>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

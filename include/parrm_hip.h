@@ -90,7 +90,7 @@ typedef struct parrm_filter_plan_info {
     int32_t phase_rows;      /* rows per thread per iteration                          */
     int32_t phase_row_slots; /* ring length in rows                                    */
     int32_t phase_residues;  /* adjacent residues per lane: 1, or 3 (the three-residue form) */
-    int32_t reserved;
+    int32_t reserved;        /* passes of a segmented plan (kernel == PARRM_KERNEL_SEGMENTED), else 0 */
 } parrm_filter_plan_info;
 
 int parrm_filter_plan_create(const double *h_filter, int64_t filter_len,

@@ -2,7 +2,8 @@
 """Randomised parity sweep of every filter_data form round 2 added, against the closed form (oracle):
 
 * resident launches with float64 and (float32 recordings) float32 output -- the packed float32 ring;
-* every kernel the plan offers (auto, gather, stride, phase, and the opt-in three-residue form);
+* every kernel the plan offers (auto -- segmented plans for the long half-widths --, gather, stride, phase, and
+  the opt-in three-residue form);
 * channel blocks cut like a larger recording (``total_chans``), compared BITWISE with the whole launch;
 * random windows (``apply_window``) and host streaming with random chunk lengths (``apply_host``);
 * non-finite samples (NaN, +-Inf) scattered into the recording: exactly the outputs a bad sample
@@ -35,7 +36,7 @@ def draw_cases(n_cases: int, seed: int):
         n_chans = int(rng.integers(1, 9))
         n_samples = int(rng.choice([1, 2, 17, 500, 5000, 40_000, 131_073, 300_000, 700_001, 1_200_000]))
         hw_max = max(1, (n_samples - 1) // 2)
-        hw = int(min(hw_max, rng.choice([3, 50, 650, 2372, 6000])))
+        hw = int(min(hw_max, rng.choice([3, 50, 650, 2372, 6000, 12000, 40000])))  # the last two: segmented plans
         omit = int(rng.integers(0, max(1, min(hw, 30))))
         direction = str(rng.choice(["both", "past", "future"]))
         phw = float(period / rng.choice([50, 20, 8]))
