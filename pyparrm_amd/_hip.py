@@ -185,6 +185,7 @@ def lib() -> C.CDLL:
 
 def _shutdown() -> None:
     _PLAN_CACHE.clear()  # plans free their device tables while the runtime is up
+    _INDEX_STAGING.clear()
     if _lib is not None:
         _lib.parrm_hip_shutdown()
 
@@ -451,6 +452,27 @@ def unpin_host(array: np.ndarray) -> None:
     """Undo :func:`pin_host` (no-op for memory that is not page-locked)."""
     require_gpu()
     check(lib().parrm_host_unpin(array.ctypes.data_as(C.c_void_p)), "parrm_host_unpin")
+
+
+_INDEX_STAGING: dict = {}
+
+
+def upload_indices(indices: np.ndarray, device):
+    """Stage sample indices (ascending int64) as a device vector.  A contiguous range -- stages 1 and 2 of the
+    period search (parrm.py:352-365) -- is generated on the device; anything else goes through a page-locked
+    staging vector kept per device (a pageable copy of 200 KB costs ~1 ms, three times per search)."""
+    torch = require_gpu()
+    idx = np.ascontiguousarray(indices, dtype=np.int64)
+    n = idx.shape[0]
+    if n and int(idx[-1]) - int(idx[0]) + 1 == n and (n < 3 or bool(np.all(idx[1:] - idx[:-1] == 1))):
+        return torch.arange(int(idx[0]), int(idx[0]) + n, dtype=torch.int64, device=device)
+    key = torch.device(device).index
+    staging = _INDEX_STAGING.get(key)
+    if staging is None or staging.shape[0] < n:
+        staging = torch.empty(max(n, 32768), dtype=torch.int64).pin_memory()
+        _INDEX_STAGING[key] = staging
+    staging[:n] = torch.from_numpy(idx)
+    return staging[:n].to(device)  # blocking: the staging vector is free again on return
 
 
 def absdiff_mean(x):

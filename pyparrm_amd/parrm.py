@@ -376,10 +376,10 @@ class PARRM:
             x = torch.from_numpy(pairs).cuda()
             compact = torch.arange(0, 2 * indices.shape[0], 2, dtype=torch.int64, device=x.device)
             y = _hip.gather_standardise(x, compact, self._d_scale, self._outlier_boundary)
-            d_idx = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64)).to(x.device)
+            d_idx = _hip.upload_indices(indices, x.device)
             return y, d_idx
         x = self._device_recording()
-        d_idx = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64)).to(x.device)
+        d_idx = _hip.upload_indices(indices, x.device)
         y = _hip.gather_standardise(x, d_idx, self._d_scale, self._outlier_boundary)
         return y, d_idx
 

@@ -16,6 +16,7 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 g = torch.Generator(device="cuda").manual_seed(1)
 shapes = [(10044, 5001, 5), (387, 10001, 10), (381, 24963, 20), (9, 24963, 20), (4, 24963, 20), (12, 5001, 5), (10, 10001, 10)]
 ws = _hip.FitWorkspace()
+arms = [a for a in sys.argv[2:]]  # NAME=VALUE settings to time beside the default (small batches only)
 for P, n, bw in shapes:
     y = torch.randn((n, C), generator=g, device="cuda", dtype=torch.float64).clamp_(-3, 3)
     idx = torch.arange(1000, 1000 + n, device="cuda", dtype=torch.int64)
@@ -28,4 +29,20 @@ for P, n, bw in shapes:
     for _ in range(reps):
         e = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
     dt = (time.perf_counter() - t0) / reps * 1e3
-    print(f"P={P:6d} n={n:6d} bw={bw:2d} C={C}: {dt:8.3f} ms per call   (finite errors: {int(np.isfinite(e).sum())})", flush=True)
+    extra = ""
+    if P <= 100:
+        for arm in arms:
+            k, v = arm.split("=", 1)
+            best = {}
+            for rnd in range(6):  # interleaved rounds
+                for name in ("default", arm):
+                    if name != "default":
+                        os.environ[k] = v
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+                    best[name] = min(best.get(name, 1e9), (time.perf_counter() - t0) / reps * 1e3)
+                    os.environ.pop(k, None)
+            extra += f"   [default {best['default']:.3f} vs {arm} {best[arm]:.3f}]"
+    print(f"P={P:6d} n={n:6d} bw={bw:2d} C={C}: {dt:8.3f} ms per call   (finite errors: {int(np.isfinite(e).sum())}){extra}", flush=True)

@@ -130,6 +130,7 @@ def _install_oracle_device(torch, orc):
     _hip.FitWorkspace = lambda: None
     _hip.FilterPlan = Plan
     _hip.to_host_numpy = lambda t: t.numpy()
+    _hip.upload_indices = lambda indices, device: torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64))
     facade.PARRM._device_recording = lambda self, data=None: torch.from_numpy(
         np.ascontiguousarray(self._data if data is None else data))
     facade.PARRM._plan_for = lambda self, device: Plan(self._filter)
