@@ -602,9 +602,16 @@ __device__ inline unsigned long long dpp_max_u64(unsigned long long v) {
     return o > v ? o : v;
 }
 
-template <int K>
-__global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
-                                                              int nz, double lambda, double *err) {
+// NW = 4: one workgroup of four waves per candidate (grids).  NW = 1, the form of the optimiser's small batches:
+// one WAVE per (candidate, 64-channel quarter of a 256-channel block), blockIdx.y = 4*zb + quarter.  Every wave
+// factorises the candidate's Gram matrix for itself -- idle CUs are free in a batch of a few candidates -- and
+// has an LDS of its own for the substitutions, where the four waves of the NW = 4 form contend for one (the
+// substitution phase is LDS-bound: 840 broadcast reads per wave).  It leaves its wave sum in a spare cell of the
+// candidate's block (row KP, columns kYCols + quarter: the y'y row has no Gram part) and fit_finish_kernel adds
+// the quarters in the order the NW = 4 form adds its waves: same bits, 58 -> 35 us per K = 41 batch.
+template <int K, int NW>
+__global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
+                                                                   int nz, double lambda, double *err) {
     constexpr int KS = 49;  // odd row stride: lanes-as-rows accesses in the LU stay bank-conflict free
     constexpr int KE = (K + 2) & ~1;  // even row stride of the substitution copy: 16-byte aligned rows
     __shared__ double A[K * KS];    // Gram matrix in, read one row per lane by the LU
@@ -617,8 +624,10 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
     const int goff = (p % (48 / KP)) * KP;
     const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
     const double *base = red + static_cast<int64_t>(p) * nz * elems;
+    const int quarter = NW == 4 ? (tid >> 6) : static_cast<int>(blockIdx.y & 3);  // 64-channel quarter of a block
+    const int ch = quarter * 64 + lane;                                             // channel within the block
 
-    for (int e = tid; e < K * K; e += 256) {
+    for (int e = tid; e < K * K; e += 64 * NW) {
         const int r = e / K, c = e % K;
         A[r * KS + c] = base[r * kNCol + kYCols + goff + c];
     }
@@ -690,22 +699,28 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
     }
     __syncthreads();
     if (singular) {
-        if (tid == 0) err[p] = INFINITY;
+        if constexpr (NW == 4) {
+            if (tid == 0) err[p] = INFINITY;
+        } else {
+            if (lane == 0)
+                const_cast<double *>(base)[(blockIdx.y >> 2) * elems + KP * kNCol + kYCols + quarter] = INFINITY;
+        }
         return;
     }
 
     const double ksum = static_cast<double>(K * (K + 1) / 2);
     double total = 0.0;
-    for (int zb = 0; zb < nz; ++zb) {
+    const int zb_lo = NW == 4 ? 0 : static_cast<int>(blockIdx.y >> 2), zb_hi = NW == 4 ? nz : zb_lo + 1;
+    for (int zb = zb_lo; zb < zb_hi; ++zb) {
         const double *rz = base + zb * elems;
         const int ncol = min(kYCols, n_chans - zb * kYCols);
         double e_c = 0.0;
-        if (tid < ncol) {
+        if (ch < ncol) {
             // b = P r: the permutation is wave-uniform, so each entry is fetched from its permuted
             // row (L2-resident); r itself is re-read for the quadratic form
             double b[K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) b[i] = rz[perm[i] * kNCol + tid];
+            for (int i = 0; i < K; ++i) b[i] = rz[perm[i] * kNCol + ch];
             // the factors are wave-uniform: every entry is an LDS broadcast read, so they are
             // fetched as aligned pairs (one ds_read_b128 per two multiply-adds)
             auto pair_at = [&](int i, int j) -> double2 {  // j even
@@ -744,19 +759,51 @@ __global__ void __launch_bounds__(256) fit_solve_fast_kernel(const double *red, 
             double t1 = 0.0, reg = 0.0;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                t1 = fma(b[i], rz[i * kNCol + tid], t1);
+                t1 = fma(b[i], rz[i * kNCol + ch], t1);
                 reg += (lambda * static_cast<double>(i + 1) / ksum) * (b[i] * b[i]);  // :585-586,:595
             }
-            const double yy = rz[KP * kNCol + tid];
+            const double yy = rz[KP * kNCol + ch];
             e_c = (yy - t1) / static_cast<double>(n_idx) + reg;
         }
         const double v = parrm::wave_sum(e_c);
-        __syncthreads();
-        if (lane == 0) wsum[tid >> 6] = v;
-        __syncthreads();
-        total += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if constexpr (NW == 4) {
+            __syncthreads();
+            if (lane == 0) wsum[tid >> 6] = v;
+            __syncthreads();
+            total += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        } else {
+            if (lane == 0) const_cast<double *>(rz)[KP * kNCol + kYCols + quarter] = v;
+        }
     }
-    if (tid == 0) err[p] = total / static_cast<double>(n_chans);  // :597
+    if constexpr (NW == 4) {
+        if (tid == 0) err[p] = total / static_cast<double>(n_chans);  // :597
+    }
+}
+
+// the channel mean of the NW = 1 form: quarters added as the NW = 4 form adds its waves, blocks in order; then, for
+// the optimiser's batches, the hand-off of fit_publish_kernel (below) in the same launch
+__global__ void __launch_bounds__(64) fit_finish_kernel(const double *red, int n, int KP, int nz, int n_chans, double *err,
+                                                         double *host_err, volatile unsigned long long *flag,
+                                                         unsigned long long seq) {
+    const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
+    for (int p = threadIdx.x; p < n; p += 64) {
+        double total = 0.0;
+        for (int zb = 0; zb < nz; ++zb) {
+            const double *q = red + (static_cast<int64_t>(p) * nz + zb) * elems + KP * kNCol + kYCols;
+            total += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+        const double e = total / static_cast<double>(n_chans);  // :597
+        err[p] = e;
+        if (host_err) host_err[p] = e;
+    }
+    if (host_err) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *flag = seq;
+            __threadfence_system();
+        }
+    }
 }
 
 struct FitGeom {
@@ -970,9 +1017,28 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
                                   d_workspace, workspace_bytes, stream);
 }
 
+// hand-off of an optimiser batch's errors to the host (parrm_fit_errors_host): when the batch takes the one-wave
+// solve, its finishing kernel publishes too and `done` is set
+struct Publish {
+    double *host_err;
+    volatile unsigned long long *flag;
+    unsigned long long seq;
+    bool done;
+};
+static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
+                           const double *d_periods, int64_t n_periods, int64_t grid_periods, int bw, double lambda,
+                           double *d_err, void *d_workspace, size_t workspace_bytes, void *stream, Publish *pub);
+
 int parrm_fit_errors_slice(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
                            const double *d_periods, int64_t n_periods, int64_t grid_periods, int bw, double lambda,
                            double *d_err, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return fit_errors_impl(d_y, ldy, d_idx, n_idx, n_chans, d_periods, n_periods, grid_periods, bw, lambda, d_err,
+                           d_workspace, workspace_bytes, stream, nullptr);
+}
+
+static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
+                           const double *d_periods, int64_t n_periods, int64_t grid_periods, int bw, double lambda,
+                           double *d_err, void *d_workspace, size_t workspace_bytes, void *stream, Publish *pub) {
     PARRM_REQUIRE(d_y && d_idx && d_periods && d_err && d_workspace, "fit_errors: NULL argument");
     PARRM_REQUIRE(grid_periods >= n_periods, "fit_errors: a slice cannot be longer than its grid");
     PARRM_REQUIRE(bw >= 0 && bw <= kMaxBw, "fit_errors: bandwidth %d outside [0, %d]", bw, kMaxBw);
@@ -1027,13 +1093,32 @@ int parrm_fit_errors_slice(const double *d_y, int64_t ldy, const int64_t *d_idx,
     }
     const int K = 2 * bw + 1;
     if (K == 11 || K == 21 || K == 41) {
+        // small batches (the optimiser's steps): one wave per 64-channel quarter, see fit_solve_fast_kernel
+        // (measured per batch, 256 channels: K = 41 222 -> 208 us at 9 candidates, 155 -> 141 us at 4; K = 21 and 11
+        // unchanged or 3 us worse -- their factorisation is short and the extra launch shows -- so K = 41 only)
+        const bool quarters = K == 41 && n_periods <= 64 && 4 * g.nz <= 65535 && !getenv("PARRM_FIT_SOLVE_ONE_WORKGROUP");
+        if (quarters) {
+            const dim3 sg(static_cast<unsigned>(n_periods), static_cast<unsigned>(4 * g.nz)), sb(64);
+            if (K == 11)
+                hipLaunchKernelGGL((fit_solve_fast_kernel<11, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            else if (K == 21)
+                hipLaunchKernelGGL((fit_solve_fast_kernel<21, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            else
+                hipLaunchKernelGGL((fit_solve_fast_kernel<41, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            PARRM_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(fit_finish_kernel, dim3(1), dim3(64), 0, s, red, P, g.KP, g.nz, C, d_err,
+                               pub ? pub->host_err : nullptr, pub ? pub->flag : nullptr, pub ? pub->seq : 0ull);
+            PARRM_HIP_CHECK(hipGetLastError());
+            if (pub) pub->done = true;
+            return PARRM_OK;
+        }
         const dim3 sg(static_cast<unsigned>(n_periods)), sb(256);
         if (K == 11)
-            hipLaunchKernelGGL(fit_solve_fast_kernel<11>, sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            hipLaunchKernelGGL((fit_solve_fast_kernel<11, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
         else if (K == 21)
-            hipLaunchKernelGGL(fit_solve_fast_kernel<21>, sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            hipLaunchKernelGGL((fit_solve_fast_kernel<21, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
         else
-            hipLaunchKernelGGL(fit_solve_fast_kernel<41>, sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            hipLaunchKernelGGL((fit_solve_fast_kernel<41, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
         PARRM_HIP_CHECK(hipGetLastError());
         return PARRM_OK;
     }
@@ -1069,15 +1154,18 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
         // which would be one uncached PCIe read per wave from mapped host memory)
         // (also measured: the periods as kernel arguments of a one-wave launch instead of this copy -- no difference)
         PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
-        const int rc = parrm_fit_errors(d_y, ldy, d_idx, n_idx, n_chans, d_per, n_periods, bw, lambda, d_err, d_workspace,
-                                        inner, stream);
-        if (rc != PARRM_OK) return rc;
         const unsigned long long seq = ++st.seq;
         volatile unsigned long long *h_flag = reinterpret_cast<volatile unsigned long long *>(st.h + 2 * HostStage::kCap);
-        hipLaunchKernelGGL(fit_publish_kernel, dim3(1), dim3(64), 0, s, d_err, static_cast<int>(n_periods),
-                           st.d + HostStage::kCap,
-                           reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap), seq);
-        PARRM_HIP_CHECK(hipGetLastError());
+        Publish pub{st.d + HostStage::kCap, reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap), seq,
+                    false};
+        const int rc = fit_errors_impl(d_y, ldy, d_idx, n_idx, n_chans, d_per, n_periods, n_periods, bw, lambda, d_err,
+                                       d_workspace, inner, stream, &pub);
+        if (rc != PARRM_OK) return rc;
+        if (!pub.done) {
+            hipLaunchKernelGGL(fit_publish_kernel, dim3(1), dim3(64), 0, s, d_err, static_cast<int>(n_periods), pub.host_err,
+                               pub.flag, seq);
+            PARRM_HIP_CHECK(hipGetLastError());
+        }
         // spin on the flag; look at the stream now and then so that a failed launch cannot hang us
         for (unsigned spins = 0; *h_flag != seq; ++spins) {
             if ((spins & 0xffff) == 0xffff) {
