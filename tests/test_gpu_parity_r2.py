@@ -793,3 +793,40 @@ def test_segmented_plan_for_half_widths_beyond_the_ring(period, hw, direction):
     assert np.all(np.isfinite(yb))
     assert np.array_equal(yb == 0, refb == 0)
     assert np.abs(yb - refb).max() <= 1e-10 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["constant_channel", "zero_recording", "inf_sample", "nan_run", "one_clean_of_three"])
+def test_find_period_on_degenerate_recordings_behaves_like_the_reference(case):
+    """Recordings on which the search cannot (or can barely) succeed: the device path must end the way the
+    reference's formulation (the oracle) ends -- the same ValueError, or the same period (parrm.py:274-280 divides
+    by a zero mean for a flat channel, :592-597 turns any NaN into a non-finite error, :317-321 / :459-463 raise)."""
+    n = 12_000
+    x = synth_recording_exact(3, n, 1000.0 / 130.0 * (1 + 2e-4), seed=31)
+    if case == "constant_channel":
+        x[1] = 4.25
+    elif case == "zero_recording":
+        x[:] = 0.0
+    elif case == "inf_sample":
+        x[0, 6000] = np.inf
+    elif case == "nan_run":
+        x[2, 5000:5100] = np.nan
+    elif case == "one_clean_of_three":
+        x[0] = 0.0
+        x[2] = -1.5
+    with np.errstate(all="ignore"):
+        try:
+            want = ("period", float(orc.find_period(x, 1000.0, 130.0, random_seed=5)))
+        except ValueError as exc:
+            want = ("error", str(exc))
+    p = PARRM(x, 1000.0, 130.0, verbose=False)
+    try:
+        p.find_period(random_seed=5)
+        got = ("period", float(p.period))
+    except ValueError as exc:
+        got = ("error", str(exc))
+    assert got[0] == want[0], (case, got, want)
+    if want[0] == "error":
+        assert got[1] == want[1]
+    else:
+        assert abs(got[1] - want[1]) <= PERIOD_RTOL * want[1]
