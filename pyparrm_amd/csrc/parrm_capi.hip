@@ -126,17 +126,6 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     if (rc != PARRM_OK) return rc;
     const int64_t hw = info.half_width;
     const size_t xs = x_dtype == PARRM_F64 ? 8 : 4, ys = y_dtype == PARRM_F64 ? 8 : 4;
-    if (chunk_samples <= 0) {
-        // ~256 MiB of input per chunk (PARRM_HOST_CHUNK_MB), but never less than a few half-widths (halo
-        // overhead <= ~12%)
-        int64_t mb = 256;
-        if (const char *env = getenv("PARRM_HOST_CHUNK_MB")) mb = std::max<int64_t>(1, atoll(env));
-        chunk_samples = std::max<int64_t>((mb << 20) / static_cast<int64_t>(xs) / n_chans, 16 * hw + 1024);
-    }
-    chunk_samples = std::min(chunk_samples, n_samples);
-    const int64_t n_chunks = (n_samples + chunk_samples - 1) / chunk_samples;
-    const int64_t buf_cap = chunk_samples + 2 * hw;
-
     StreamRes r;
     // chunks in flight: the upload of chunk k+1 overlaps the kernel and the download of chunk k.  Measured
     // (128 ch x 20 M f32 -> f32, scripts/cfg5_sweep.sh): 2 lanes x 256 MiB chunks 82 GB/s over PCIe (in + out);
@@ -144,7 +133,6 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     // PARRM_HOST_LANES / PARRM_HOST_CHUNK_MB: tuning knobs.
     int lanes = 2;
     if (const char *env = getenv("PARRM_HOST_LANES")) lanes = std::max(1, std::min(kMaxLanes, atoi(env)));
-    const int nbuf = static_cast<int>(std::min<int64_t>(n_chunks, lanes));
     const size_t x_bytes = static_cast<size_t>((n_chans - 1) * ldx + n_samples) * xs;
     const size_t y_bytes = static_cast<size_t>((n_chans - 1) * ldy + n_samples) * ys;
     constexpr size_t kLockInPlaceMin = size_t{64} << 20;
@@ -166,6 +154,19 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
         if (locked_x) (void)hipHostUnregister(const_cast<void *>(h_x));
         if (locked_y) (void)hipHostUnregister(h_y);
     };
+    if (chunk_samples <= 0) {
+        // ~256 MiB of input per chunk when both buffers are used in place (PARRM_HOST_CHUNK_MB), 4 MiB when a side is
+        // staged (the staging buffers are page-locked allocations of two chunks each, and the calling thread's copies
+        // only overlap the device's work chunk by chunk: 8 ch x 1 M float64 8.5 ms at 4 MiB, 12.4 at 16, 17.5 at 256;
+        // scripts/bench_host_staged.py); never less than a few half-widths (halo overhead <= ~12%)
+        int64_t mb = direct_x && direct_y ? 256 : 4;
+        if (const char *env = getenv("PARRM_HOST_CHUNK_MB")) mb = std::max<int64_t>(1, atoll(env));
+        chunk_samples = std::max<int64_t>((mb << 20) / static_cast<int64_t>(xs) / n_chans, 16 * hw + 1024);
+    }
+    chunk_samples = std::min(chunk_samples, n_samples);
+    const int64_t n_chunks = (n_samples + chunk_samples - 1) / chunk_samples;
+    const int64_t buf_cap = chunk_samples + 2 * hw;
+    const int nbuf = static_cast<int>(std::min<int64_t>(n_chunks, lanes));
     hipError_t e = hipSuccess;
     for (int i = 0; i < nbuf && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&r.stream[i], hipStreamNonBlocking);
