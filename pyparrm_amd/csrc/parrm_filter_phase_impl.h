@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(1024) filter_phase_kernel(FilterArgs a, PhaseG
     }
 }
 
-int pad_half(int64_t n) {
+[[maybe_unused]] int pad_half(int64_t n) {
     for (int d : {4, 8, 12, 14, 16, 20, 24, 32})
         if (n <= d) return d;
     return 0;
