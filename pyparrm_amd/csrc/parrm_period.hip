@@ -85,6 +85,16 @@ __global__ void __launch_bounds__(256) gather_kernel(const T *x, int64_t n_chans
 constexpr int kTJ = 16;      // samples per LDS tile
 constexpr int kYCols = 256;  // data columns per workgroup
 constexpr int kNCol = 320;   // + up to 64 columns holding W itself (-> Gram matrix)
+
+// Block coordinates of a kernel body.  The fit kernels below are written as __device__ bodies over explicit block
+// coordinates with two kinds of __global__ wrappers: the plain one (coordinates = blockIdx) and the "gang" one of
+// parrm_fit_errors_multi, where blockIdx.z picks one of several independent problems from a device table.
+struct Blk {
+    int x, y, z, nz;
+};
+__device__ inline Blk this_block() {
+    return Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), static_cast<int>(blockIdx.z), static_cast<int>(gridDim.z)};
+}
 constexpr int kMaxBw = 23;
 
 __host__ __device__ inline int kp_for(int bw) {  // padded row count: 4 waves x KT rows
@@ -134,15 +144,14 @@ __global__ void __launch_bounds__(256) fit_trig_kernel(const int64_t *idx, int n
 // 128-byte segments).  One workgroup = 64 samples x the NCB candidates of one stack (wave q =
 // candidate q): the 64 x 48 block is assembled in LDS and written out as one contiguous 24 KB run.
 // Candidates >= n_periods and samples >= n_idx are zeros.
-__global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const int64_t *idx, int n_idx, int n_pad,
-                                                                const double *periods, int n_periods, int bw,
-                                                                int kpc, int exact, double *Ws) {
+__device__ __forceinline__ void fit_trig_stacked_body(const int64_t *idx, int n_idx, int n_pad, const double *periods,
+                                                      int n_periods, int bw, int kpc, int exact, double *Ws, const Blk blk) {
     constexpr int KS = 48, TS = 49;  // padded tile row: conflict-free b64 writes at one row per lane
     __shared__ double tile[64 * TS];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int ncb = KS / kpc;
-    const int j = blockIdx.x * 64 + lane;
-    const int p = blockIdx.y * ncb + q;
+    const int j = blk.x * 64 + lane;
+    const int p = blk.y * ncb + q;
     const int K = 2 * bw + 1;
     double *t = tile + lane * TS + q * kpc;
     if (j >= n_idx || p >= n_periods) {
@@ -166,9 +175,14 @@ __global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const int64_t *id
         for (int k = K; k < kpc; ++k) t[k] = 0.0;
     }
     __syncthreads();
-    const int rows = min(64, n_pad - blockIdx.x * 64);  // n_pad is a multiple of 16
-    double *dst = Ws + (static_cast<int64_t>(blockIdx.y) * n_pad + static_cast<int64_t>(blockIdx.x) * 64) * KS;
+    const int rows = min(64, n_pad - blk.x * 64);  // n_pad is a multiple of 16
+    double *dst = Ws + (static_cast<int64_t>(blk.y) * n_pad + static_cast<int64_t>(blk.x) * 64) * KS;
     for (int e = threadIdx.x; e < rows * KS; e += blockDim.x) dst[e] = tile[(e / KS) * TS + (e % KS)];
+}
+__global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const int64_t *idx, int n_idx, int n_pad,
+                                                                const double *periods, int n_periods, int bw,
+                                                                int kpc, int exact, double *Ws) {
+    fit_trig_stacked_body(idx, n_idx, n_pad, periods, n_periods, bw, kpc, exact, Ws, this_block());
 }
 
 // ---- Gram blocks -----------------------------------------------------------------------------
@@ -295,14 +309,14 @@ typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 // recordings of <= 64 channels (one wave takes the 64 data columns and all nine Gram tiles: 21 MFMAs
 // per step instead of 60 -- few-channel recordings are the common case in practice).
 template <int NW>
-__global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, int64_t ldy, const double *Ws,
-                                                              int n_pad, int n_idx, int n_chans, int n_periods,
-                                                              int kpc, int nsplit, double *part) {
+__device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy, const double *Ws, int n_pad, int n_idx,
+                                                    int n_chans, int n_periods, int kpc, int nsplit, double *part,
+                                                    const Blk blk) {
     constexpr int KS = 48, D = 4, NG = NW == 4 ? 1 : 3;  // Gram row-tiles per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = NW == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const int c = lane & 15, sj = lane >> 4;
-    const int sl = blockIdx.x, pb = blockIdx.y, zb = blockIdx.z, nz = gridDim.z;
+    const int sl = blk.x, pb = blk.y, zb = blk.z, nz = blk.nz;
     const int ncb = KS / kpc;
 
     const int tiles = n_pad / kTJ;
@@ -431,14 +445,20 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
         }
     }
 }
+template <int NW>
+__global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, int64_t ldy, const double *Ws,
+                                                              int n_pad, int n_idx, int n_chans, int n_periods,
+                                                              int kpc, int nsplit, double *part) {
+    fit_accum_mfma_body<NW>(Y, ldy, Ws, n_pad, n_idx, n_chans, n_periods, kpc, nsplit, part, this_block());
+}
 
 // red[(p*nz+zb)][e] = sum_s part[(p*nz+zb)][s][e], s ascending (deterministic)
 // (data columns beyond the recording's channels are never read by the solvers: skipped)
-__global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int nsplit, int64_t elems, int nz,
-                                                          int n_chans, double *red) {
-    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fit_reduce_body(const double *part, int nsplit, int64_t elems, int nz, int n_chans,
+                                                double *red, const Blk blk) {
+    const int64_t e = static_cast<int64_t>(blk.x) * blockDim.x + threadIdx.x;
     if (e >= elems) return;
-    const int64_t pz = blockIdx.y;
+    const int64_t pz = blk.y;
     const int col = static_cast<int>(e % kNCol), zb = static_cast<int>(pz % nz);
     if (col < kYCols && zb * kYCols + col >= n_chans) return;
     const double *src = part + pz * nsplit * elems + e;
@@ -455,6 +475,10 @@ __global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int
     }
     for (; s < nsplit; ++s) a += src[static_cast<int64_t>(s) * elems];
     red[pz * elems + e] = a;
+}
+__global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int nsplit, int64_t elems, int nz,
+                                                          int n_chans, double *red) {
+    fit_reduce_body(part, nsplit, elems, nz, n_chans, red, this_block());
 }
 
 // One workgroup per candidate period: LU(G) with partial pivoting, solve for every channel,
@@ -610,8 +634,8 @@ __device__ inline unsigned long long dpp_max_u64(unsigned long long v) {
 // candidate's block (row KP, columns kYCols + quarter: the y'y row has no Gram part) and fit_finish_kernel adds
 // the quarters in the order the NW = 4 form adds its waves: same bits, 58 -> 35 us per K = 41 batch.
 template <int K, int NW>
-__global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
-                                                                   int nz, double lambda, double *err) {
+__device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx, int n_chans, int KP, int nz, double lambda,
+                                                    double *err, const Blk blk) {
     constexpr int KS = 49;  // odd row stride: lanes-as-rows accesses in the LU stay bank-conflict free
     constexpr int KE = (K + 2) & ~1;  // even row stride of the substitution copy: 16-byte aligned rows
     __shared__ double A[K * KS];    // Gram matrix in, read one row per lane by the LU
@@ -620,11 +644,11 @@ __global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *r
     __shared__ int singular;
     __shared__ double wsum[4];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int p = blockIdx.x;
+    const int p = blk.x;
     const int goff = (p % (48 / KP)) * KP;
     const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
     const double *base = red + static_cast<int64_t>(p) * nz * elems;
-    const int quarter = NW == 4 ? (tid >> 6) : static_cast<int>(blockIdx.y & 3);  // 64-channel quarter of a block
+    const int quarter = NW == 4 ? (tid >> 6) : static_cast<int>(blk.y & 3);  // 64-channel quarter of a block
     const int ch = quarter * 64 + lane;                                             // channel within the block
 
     for (int e = tid; e < K * K; e += 64 * NW) {
@@ -703,14 +727,14 @@ __global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *r
             if (tid == 0) err[p] = INFINITY;
         } else {
             if (lane == 0)
-                const_cast<double *>(base)[(blockIdx.y >> 2) * elems + KP * kNCol + kYCols + quarter] = INFINITY;
+                const_cast<double *>(base)[(blk.y >> 2) * elems + KP * kNCol + kYCols + quarter] = INFINITY;
         }
         return;
     }
 
     const double ksum = static_cast<double>(K * (K + 1) / 2);
     double total = 0.0;
-    const int zb_lo = NW == 4 ? 0 : static_cast<int>(blockIdx.y >> 2), zb_hi = NW == 4 ? nz : zb_lo + 1;
+    const int zb_lo = NW == 4 ? 0 : static_cast<int>(blk.y >> 2), zb_hi = NW == 4 ? nz : zb_lo + 1;
     for (int zb = zb_lo; zb < zb_hi; ++zb) {
         const double *rz = base + zb * elems;
         const int ncol = min(kYCols, n_chans - zb * kYCols);
@@ -779,6 +803,11 @@ __global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *r
         if (tid == 0) err[p] = total / static_cast<double>(n_chans);  // :597
     }
 }
+template <int K, int NW>
+__global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
+                                                                   int nz, double lambda, double *err) {
+    fit_solve_fast_body<K, NW>(red, n_idx, n_chans, KP, nz, lambda, err, this_block());
+}
 
 // the channel mean of the NW = 1 form: quarters added as the NW = 4 form adds its waves, blocks in order; then, for
 // the optimiser's batches, the hand-off of fit_publish_kernel (below) in the same launch
@@ -803,6 +832,79 @@ __global__ void __launch_bounds__(64) fit_finish_kernel(const double *red, int n
             *flag = seq;
             __threadfence_system();
         }
+    }
+}
+
+// ---- gang launches: several independent problems per launch (parrm_fit_errors_multi) -----------------------------
+// Per-site period estimation (examples/plot_example_dbs_data.py:52-98) advances many small searches in lock-step.
+// Launching every search's five kernels on a side stream of its own left the call bound by launch and dispatch
+// overhead (~107 us per search and step for single-channel sites).  Here blockIdx.z picks the problem from a
+// device table and every block runs the single-problem kernel body on it -- same geometry per problem (the sample
+// split is planned per problem, as for a call of its own), same arithmetic, one launch per kernel for the gang.
+struct GangProblem {
+    const double *y;
+    const int64_t *idx;
+    const double *periods;
+    double *wmat, *part, *red, *err;
+    int64_t ldy;
+    double lambda;
+    int n_idx, n_pad, n_chans, n_periods, nsplit, groups, trig_blocks, err_off;
+};
+
+__global__ void __launch_bounds__(256) fit_trig_stacked_gang(const GangProblem *tab, int bw, int kpc, int exact) {
+    const GangProblem &q = tab[blockIdx.z];
+    if (static_cast<int>(blockIdx.x) >= q.trig_blocks || static_cast<int>(blockIdx.y) >= q.groups) return;
+    fit_trig_stacked_body(q.idx, q.n_idx, q.n_pad, q.periods, q.n_periods, bw, kpc, exact, q.wmat,
+                          Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+}
+
+template <int NW>
+__global__ void __launch_bounds__(256) fit_accum_mfma_gang(const GangProblem *tab, int kpc) {
+    const GangProblem &q = tab[blockIdx.z];
+    if (static_cast<int>(blockIdx.x) >= q.nsplit || static_cast<int>(blockIdx.y) >= q.groups) return;
+    fit_accum_mfma_body<NW>(q.y, q.ldy, q.wmat, q.n_pad, q.n_idx, q.n_chans, q.n_periods, kpc, q.nsplit, q.part,
+                            Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+}
+
+__global__ void __launch_bounds__(256) fit_reduce_gang(const GangProblem *tab, int64_t elems) {
+    const GangProblem &q = tab[blockIdx.z];
+    if (q.nsplit == 1 || static_cast<int>(blockIdx.y) >= q.n_periods) return;
+    fit_reduce_body(q.part, q.nsplit, elems, 1, q.n_chans, q.red, Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+}
+
+template <int K, int NW>
+__global__ void __launch_bounds__(64 * NW) fit_solve_fast_gang(const GangProblem *tab, int KP) {
+    const GangProblem &q = tab[blockIdx.z];
+    if (static_cast<int>(blockIdx.x) >= q.n_periods) return;
+    fit_solve_fast_body<K, NW>(q.red, q.n_idx, q.n_chans, KP, 1, q.lambda, q.err,
+                               Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+}
+
+// one workgroup for the whole call: quarter sums -> errors where the one-wave solve ran (K = 41), every problem's
+// errors into the page-locked hand-off block, then ONE flag
+__global__ void __launch_bounds__(64) fit_publish_gang(const GangProblem *tab, int n_problems, const int *quarters_kp,
+                                                        double *host_err, volatile unsigned long long *flag,
+                                                        unsigned long long seq) {
+    for (int pr = 0; pr < n_problems; ++pr) {
+        const GangProblem &q = tab[pr];
+        const int KP = quarters_kp[pr];  // > 0: the problem's solve left quarter sums (row KP of its blocks)
+        for (int p = threadIdx.x; p < q.n_periods; p += 64) {
+            double e;
+            if (KP > 0) {
+                const double *cell = q.red + static_cast<int64_t>(p) * (KP + 1) * kNCol + KP * kNCol + kYCols;
+                e = ((cell[0] + cell[1]) + (cell[2] + cell[3])) / static_cast<double>(q.n_chans);  // :597
+                q.err[p] = e;
+            } else {
+                e = q.err[p];
+            }
+            host_err[q.err_off + p] = e;
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *flag = seq;
+        __threadfence_system();
     }
 }
 
@@ -873,6 +975,9 @@ struct HostStage {
     static constexpr int kStreams = 8;       // side streams the problems of one call are dealt over
     double *h = nullptr;                   // [kCap] periods (multi) | [kCap] errors | flag | [kMaxProblems] flags (multi)
     double *d = nullptr;                   // the same block through the device's mapping
+    // gang launches: problem table | quarter flags | periods, page-locked on the host and its device copy
+    static constexpr size_t kGangBytes = kMaxProblems * (sizeof(GangProblem) + sizeof(int)) + kCap * sizeof(double);
+    unsigned char *h_gang = nullptr, *d_gang = nullptr;
     int device = -1;
     unsigned long long seq = 0;
     hipStream_t side[kStreams] = {};
@@ -888,7 +993,22 @@ struct HostStage {
         fork = nullptr;
         if (h) (void)hipHostFree(h);
         h = d = nullptr;
+        if (h_gang) (void)hipHostFree(h_gang);
+        if (d_gang) (void)hipFree(d_gang);
+        h_gang = d_gang = nullptr;
         device = -1;
+    }
+    bool gang_ready() {
+        if (h_gang && d_gang) return true;
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, kGangBytes, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipMalloc(&dp, kGangBytes) != hipSuccess) {
+            (void)hipHostFree(hp);
+            return false;
+        }
+        h_gang = static_cast<unsigned char *>(hp);
+        d_gang = static_cast<unsigned char *>(dp);
+        return true;
     }
     bool streams_ready() {
         if (fork) return true;
@@ -1019,6 +1139,11 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
 
 // hand-off of an optimiser batch's errors to the host (parrm_fit_errors_host): when the batch takes the one-wave
 // solve, its finishing kernel publishes too and `done` is set
+static int exact_trig_mode() {
+    static const int mode = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
+    return mode;
+}
+
 struct Publish {
     double *host_err;
     volatile unsigned long long *flag;
@@ -1058,7 +1183,7 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
     double *part = wmat + g.w_bytes / sizeof(double);
     double *red = g.nsplit > 1 ? part + g.part_bytes / sizeof(double) : part;
     const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans), P = static_cast<int>(n_periods);
-    static const int exact_trig = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
+    const int exact_trig = exact_trig_mode();
     const int ncb = 48 / g.KP;
     const int groups = (P + ncb - 1) / ncb;
     // matrix-core path: needs 16-byte aligned column quads (even ldy) and 31-bit byte offsets; else the
@@ -1193,6 +1318,152 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
     return PARRM_OK;
 }
 
+// Gang form of parrm_fit_errors_multi (see GangProblem): returns PARRM_OK with *handled = false when the problems do
+// not all fit it (more than 256 channels, operands the matrix-core kernel cannot take, bandwidths without a fast
+// solve) -- the caller then takes the one-stream-per-problem form.
+static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, HostStage &st, hipStream_t s, bool *handled) {
+    *handled = false;
+    if (getenv("PARRM_FIT_MULTI_STREAMS") || !st.gang_ready()) return PARRM_OK;
+    const char *accum_env = getenv("PARRM_FIT_ACCUM");
+    if (accum_env && atoi(accum_env) == 1) return PARRM_OK;
+    struct Shape {
+        FitGeom g;
+        size_t inner;
+    };
+    std::vector<Shape> shape(n_problems);
+    for (int p = 0; p < n_problems; ++p) {
+        const parrm_fit_problem &q = problems[p];
+        const int K = 2 * q.bw + 1;
+        if (q.n_chans > kYCols || !(K == 11 || K == 21 || K == 41)) return PARRM_OK;
+        shape[p].g = fit_geometry(q.n_idx, q.n_chans, q.n_periods, q.bw);
+        shape[p].inner = parrm_fit_workspace_bytes(q.n_idx, q.n_chans, q.n_periods, q.bw);
+        const bool mfma_ok = q.ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(q.d_y) & 15) == 0 &&
+                             q.n_idx * q.ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(shape[p].g.n_pad) * 48 * 8 < 0x7fff0000LL;
+        if (!mfma_ok || q.n_idx >= (int64_t{1} << 30)) return PARRM_OK;
+    }
+    // host image: table | quarter flags | periods
+    GangProblem *tab = reinterpret_cast<GangProblem *>(st.h_gang);
+    int *quarters = reinterpret_cast<int *>(st.h_gang + HostStage::kMaxProblems * sizeof(GangProblem));
+    double *h_per = reinterpret_cast<double *>(st.h_gang + HostStage::kMaxProblems * (sizeof(GangProblem) + sizeof(int)));
+    const GangProblem *d_tab = reinterpret_cast<const GangProblem *>(st.d_gang);
+    const int *d_quarters = reinterpret_cast<const int *>(st.d_gang + HostStage::kMaxProblems * sizeof(GangProblem));
+    const double *d_per = reinterpret_cast<const double *>(st.d_gang + HostStage::kMaxProblems * (sizeof(GangProblem) + sizeof(int)));
+    // Problems of one launch share bandwidth, kernel variant and -- roughly -- grid extents: a launch spans the
+    // largest extents of its problems and every block outside a problem's own extents is dispatched just to return,
+    // which is not free (a Nelder-Mead step of 10 candidates in 64 slices beside seven 330-candidate grids in 2
+    // slices made 190 K empty workgroups: 33 ms).  Key: bandwidth, one-wave or four-wave Gram kernel, sample split,
+    // power-of-two bucket of the candidate count.
+    std::vector<int> order(n_problems);
+    for (int p = 0; p < n_problems; ++p) order[p] = p;
+    auto bucket = [](int64_t v) {
+        int b = 0;
+        while ((int64_t{1} << b) < v) ++b;
+        return b;
+    };
+    auto key = [&](int p) {
+        return ((static_cast<int64_t>(problems[p].bw) * 2 + (problems[p].n_chans <= 64 ? 0 : 1)) * 128 + shape[p].g.nsplit) * 64 +
+               bucket(problems[p].n_periods);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+    std::vector<int64_t> err_off(n_problems);
+    int64_t off = 0;
+    for (int p = 0; p < n_problems; ++p) {
+        err_off[p] = off;
+        off += problems[p].n_periods;
+    }
+    for (int slot = 0; slot < n_problems; ++slot) {
+        const int p = order[slot];
+        const parrm_fit_problem &q = problems[p];
+        const FitGeom &g = shape[p].g;
+        double *wmat = static_cast<double *>(q.d_workspace);
+        double *part = wmat + g.w_bytes / sizeof(double);
+        double *d_err = reinterpret_cast<double *>(static_cast<char *>(q.d_workspace) + shape[p].inner) + q.n_periods;
+        std::memcpy(h_per + err_off[p], q.h_periods, q.n_periods * sizeof(double));
+        GangProblem &t = tab[slot];
+        t.y = q.d_y;
+        t.idx = q.d_idx;
+        t.periods = d_per + err_off[p];
+        t.wmat = wmat;
+        t.part = part;
+        t.red = g.nsplit > 1 ? part + g.part_bytes / sizeof(double) : part;
+        t.err = d_err;
+        t.ldy = q.ldy;
+        t.lambda = q.lambda;
+        t.n_idx = static_cast<int>(q.n_idx);
+        t.n_pad = g.n_pad;
+        t.n_chans = static_cast<int>(q.n_chans);
+        t.n_periods = static_cast<int>(q.n_periods);
+        t.nsplit = g.nsplit;
+        const int ncb = 48 / g.KP;
+        t.groups = (t.n_periods + ncb - 1) / ncb;
+        t.trig_blocks = (g.n_pad + 63) / 64;
+        t.err_off = static_cast<int>(err_off[p]);
+        quarters[slot] = (2 * q.bw + 1 == 41 && !getenv("PARRM_FIT_SOLVE_ONE_WORKGROUP")) ? g.KP : 0;
+    }
+    PARRM_HIP_CHECK(hipMemcpyAsync(st.d_gang, st.h_gang, HostStage::kGangBytes, hipMemcpyHostToDevice, s));
+    const int exact = exact_trig_mode();
+    for (int lo = 0; lo < n_problems;) {
+        int hi = lo;
+        while (hi < n_problems && key(order[hi]) == key(order[lo])) ++hi;
+        const parrm_fit_problem &q0 = problems[order[lo]];
+        const int bw = q0.bw, K = 2 * bw + 1, KP = kp_for(bw), ncb = 48 / KP;
+        const bool narrow = q0.n_chans <= 64;
+        int max_trig = 0, max_groups = 0, max_split = 0, max_p = 0;
+        bool any_split = false;
+        for (int slot = lo; slot < hi; ++slot) {
+            const GangProblem &t = tab[slot];
+            max_trig = std::max(max_trig, t.trig_blocks);
+            max_groups = std::max(max_groups, t.groups);
+            max_split = std::max(max_split, t.nsplit);
+            max_p = std::max(max_p, t.n_periods);
+            any_split = any_split || t.nsplit > 1;
+        }
+        const unsigned nz = static_cast<unsigned>(hi - lo);
+        const GangProblem *sub = d_tab + lo;
+        hipLaunchKernelGGL(fit_trig_stacked_gang, dim3(max_trig, max_groups, nz), dim3(64 * ncb), 0, s, sub, bw, KP, exact);
+        if (narrow)
+            hipLaunchKernelGGL(fit_accum_mfma_gang<1>, dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
+        else
+            hipLaunchKernelGGL(fit_accum_mfma_gang<4>, dim3(max_split, max_groups, nz), dim3(256), 0, s, sub, KP);
+        const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
+        if (any_split)
+            hipLaunchKernelGGL(fit_reduce_gang, dim3(static_cast<unsigned>((elems + 255) / 256), max_p, nz), dim3(256), 0, s, sub, elems);
+        if (K == 11)
+            hipLaunchKernelGGL((fit_solve_fast_gang<11, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP);
+        else if (K == 21)
+            hipLaunchKernelGGL((fit_solve_fast_gang<21, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP);
+        else if (quarters[lo] > 0)
+            hipLaunchKernelGGL((fit_solve_fast_gang<41, 1>), dim3(max_p, 4, nz), dim3(64), 0, s, sub, KP);
+        else
+            hipLaunchKernelGGL((fit_solve_fast_gang<41, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP);
+        PARRM_HIP_CHECK(hipGetLastError());
+        lo = hi;
+    }
+    const unsigned long long seq = ++st.seq;
+    volatile unsigned long long *h_flag = reinterpret_cast<volatile unsigned long long *>(st.h + 2 * HostStage::kCap);
+    hipLaunchKernelGGL(fit_publish_gang, dim3(1), dim3(64), 0, s, d_tab, n_problems, d_quarters, st.d + HostStage::kCap,
+                       reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap), seq);
+    PARRM_HIP_CHECK(hipGetLastError());
+    for (unsigned spins = 0; *h_flag != seq; ++spins) {
+        if ((spins & 0xffff) == 0xffff) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) {
+                if (*h_flag == seq) break;
+                PARRM_HIP_CHECK(hipStreamSynchronize(s));
+                PARRM_REQUIRE(*h_flag == seq, "fit_errors_multi: the stream drained without publishing the errors");
+                break;
+            }
+            if (e != hipErrorNotReady) return parrm::hip_fail(e, "fit_errors_multi: stream");
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int p = 0; p < n_problems; ++p)
+        std::memcpy(problems[p].h_err, st.h + HostStage::kCap + err_off[p], problems[p].n_periods * sizeof(double));
+    *handled = true;
+    return PARRM_OK;
+}
+
 int parrm_fit_errors_multi(const parrm_fit_problem *problems, int n_problems, void *stream) {
     PARRM_REQUIRE(problems && n_problems > 0 && n_problems <= HostStage::kMaxProblems,
                   "fit_errors_multi: 1..%d problems per call", HostStage::kMaxProblems);
@@ -1217,6 +1488,11 @@ int parrm_fit_errors_multi(const parrm_fit_problem *problems, int n_problems, vo
         return PARRM_ERR_HIP;
     }
     hipStream_t s = parrm::as_stream(stream);
+    {
+        bool handled = false;
+        const int rc = fit_errors_gang(problems, n_problems, st, s, &handled);
+        if (rc != PARRM_OK || handled) return rc;
+    }
     const unsigned long long seq = ++st.seq;
     volatile unsigned long long *h_flags = reinterpret_cast<volatile unsigned long long *>(st.h + 2 * HostStage::kCap + 8);
     volatile unsigned long long *d_flags = reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap + 8);
