@@ -308,10 +308,11 @@ typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 // NW = waves per workgroup: 4 (256 data columns; the Gram row-tiles spread over waves 0-2), or 1 for
 // recordings of <= 64 channels (one wave takes the 64 data columns and all nine Gram tiles: 21 MFMAs
 // per step instead of 60 -- few-channel recordings are the common case in practice).
-template <int NW>
+template <int NW, int CT>
 __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy, const double *Ws, int n_pad, int n_idx,
                                                     int n_chans, int n_periods, int kpc, int nsplit, double *part,
                                                     const Blk blk) {
+    static_assert(CT == 4 || (CT == 1 && NW == 1), "CT = 1: the one-wave form for <= 16 channels");
     constexpr int KS = 48, D = 4, NG = NW == 4 ? 1 : 3;  // Gram row-tiles per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = NW == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -329,7 +330,7 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         static_cast<int>((static_cast<int64_t>(n_idx) * ldy - static_cast<int64_t>(zb) * kYCols) * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(Ws) + static_cast<int64_t>(pb) * n_pad * KS, 0, n_pad * KS * 8, 0x00020000);
-    const int col0 = 64 * wv + 4 * c;                  // first of this lane's four data columns
+    const int col0 = CT == 4 ? 64 * wv + 4 * c : c;    // first of this lane's four data columns (CT = 1: its only one)
     // a quad may straddle n_chans: its extra columns come from the row's padding (or, with a tight
     // ldy, from the next row / the zero tail) and land in result columns that nothing reads
     const bool col_ok = zb * kYCols + col0 < n_chans;
@@ -337,25 +338,31 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
     unsigned vw = static_cast<unsigned>(((u_lo * 4 + sj) * KS + c) * 8);
 
-    d4_t acc[3][4], gacc[NG][3];
-    double yy[4] = {0.0, 0.0, 0.0, 0.0};
+    d4_t acc[3][CT], gacc[NG][3];
+    double yy[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) yy[t] = 0.0;
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[rt][t] = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < CT; ++t) acc[rt][t] = d4_t{0.0, 0.0, 0.0, 0.0};
     }
 #pragma unroll
     for (int gr = 0; gr < NG; ++gr)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) gacc[gr][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
-    double ra[D][3], ry[D][4];
+    double ra[D][3], ry[D][CT];
     auto fetch = [&](int d) {
-        const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
-        const u4_t y23 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy + 16, 0, 0);
-        ry[d][0] = __builtin_bit_cast(double, u2_t{y01.x, y01.y});
-        ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
-        ry[d][2] = __builtin_bit_cast(double, u2_t{y23.x, y23.y});
-        ry[d][3] = __builtin_bit_cast(double, u2_t{y23.z, y23.w});
+        if constexpr (CT == 4) {
+            const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
+            const u4_t y23 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy + 16, 0, 0);
+            ry[d][0] = __builtin_bit_cast(double, u2_t{y01.x, y01.y});
+            ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
+            ry[d][2] = __builtin_bit_cast(double, u2_t{y23.x, y23.y});
+            ry[d][3] = __builtin_bit_cast(double, u2_t{y23.z, y23.w});
+        } else {
+            ry[d][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_y, vy, 0, 0));
+        }
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt)
             ra[d][rt] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw + rt * 128, 0, 0));
@@ -367,20 +374,19 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     for (int u = u_lo; u < u_hi; u += D) {  // the slice is whole 16-sample tiles: a multiple of D steps
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            double a[3], y[4];
+            double a[3], y[CT];
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt) a[rt] = ra[d][rt];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) y[t] = ry[d][t];
+            for (int t = 0; t < CT; ++t) y[t] = ry[d][t];
             fetch(d);  // step u + d + D (past the end of the data: zeros)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < CT; ++t) {
                 yy[t] = fma(y[t], y[t], yy[t]);
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt)
                     acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
             }
-#ifndef PARRM_EXP_NO_GRAM
             if constexpr (NW == 4) {
                 // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
                 // compiler shuttle the Gram accumulators between register files every step)
@@ -395,12 +401,11 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
                     for (int ct = 0; ct < 3; ++ct)
                         gacc[gr][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gr], a[ct], gacc[gr][ct], 0, 0, 0);
             }
-#endif
         }
     }
     // y'y: the four sample lanes of a column hold partial sums
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < CT; ++t) {
         yy[t] += __shfl_xor(yy[t], 16);
         yy[t] += __shfl_xor(yy[t], 32);
     }
@@ -417,7 +422,7 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             if (pc >= n_periods) continue;
             double *row = block_of(pc) + static_cast<int64_t>(r % kpc) * kNCol;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) row[col0 + t] = acc[rt][t][v];
+            for (int t = 0; t < CT; ++t) row[col0 + t] = acc[rt][t][v];
         }
     }
     if (wv < 3) {
@@ -441,15 +446,15 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             if (pc >= n_periods) break;
             double *row = block_of(pc) + static_cast<int64_t>(kpc) * kNCol;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) row[col0 + t] = yy[t];
+            for (int t = 0; t < CT; ++t) row[col0 + t] = yy[t];
         }
     }
 }
-template <int NW>
+template <int NW, int CT = 4>
 __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, int64_t ldy, const double *Ws,
                                                               int n_pad, int n_idx, int n_chans, int n_periods,
                                                               int kpc, int nsplit, double *part) {
-    fit_accum_mfma_body<NW>(Y, ldy, Ws, n_pad, n_idx, n_chans, n_periods, kpc, nsplit, part, this_block());
+    fit_accum_mfma_body<NW, CT>(Y, ldy, Ws, n_pad, n_idx, n_chans, n_periods, kpc, nsplit, part, this_block());
 }
 
 // red[(p*nz+zb)][e] = sum_s part[(p*nz+zb)][s][e], s ascending (deterministic)
@@ -858,11 +863,11 @@ __global__ void __launch_bounds__(256) fit_trig_stacked_gang(const GangProblem *
                           Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
 }
 
-template <int NW>
+template <int NW, int CT = 4>
 __global__ void __launch_bounds__(256) fit_accum_mfma_gang(const GangProblem *tab, int kpc) {
     const GangProblem &q = tab[blockIdx.z];
     if (static_cast<int>(blockIdx.x) >= q.nsplit || static_cast<int>(blockIdx.y) >= q.groups) return;
-    fit_accum_mfma_body<NW>(q.y, q.ldy, q.wmat, q.n_pad, q.n_idx, q.n_chans, q.n_periods, kpc, q.nsplit, q.part,
+    fit_accum_mfma_body<NW, CT>(q.y, q.ldy, q.wmat, q.n_pad, q.n_idx, q.n_chans, q.n_periods, kpc, q.nsplit, q.part,
                             Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
 }
 
@@ -1201,7 +1206,11 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
                            bw, g.KP, exact_trig, wmat);
     PARRM_HIP_CHECK(hipGetLastError());
     const dim3 grid(g.nsplit, groups, g.nz);
-    if (use_mfma && C <= 64)
+    const bool narrow16 = C <= 16 && !getenv("PARRM_FIT_NO_NARROW16");
+    if (use_mfma && narrow16)
+        hipLaunchKernelGGL((fit_accum_mfma_kernel<1, 1>), grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
+                           part);
+    else if (use_mfma && C <= 64)
         hipLaunchKernelGGL(fit_accum_mfma_kernel<1>, grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
                            part);
     else if (use_mfma)
@@ -1355,13 +1364,15 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
     // power-of-two bucket of the candidate count.
     std::vector<int> order(n_problems);
     for (int p = 0; p < n_problems; ++p) order[p] = p;
+    const bool no16 = getenv("PARRM_FIT_NO_NARROW16") != nullptr;
+    auto width_class = [&](int64_t c) { return c <= 16 && !no16 ? 0 : (c <= 64 ? 1 : 2); };
     auto bucket = [](int64_t v) {
         int b = 0;
         while ((int64_t{1} << b) < v) ++b;
         return b;
     };
     auto key = [&](int p) {
-        return ((static_cast<int64_t>(problems[p].bw) * 2 + (problems[p].n_chans <= 64 ? 0 : 1)) * 128 + shape[p].g.nsplit) * 64 +
+        return ((static_cast<int64_t>(problems[p].bw) * 4 + width_class(problems[p].n_chans)) * 128 + shape[p].g.nsplit) * 64 +
                bucket(problems[p].n_periods);
     };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
@@ -1407,7 +1418,7 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         while (hi < n_problems && key(order[hi]) == key(order[lo])) ++hi;
         const parrm_fit_problem &q0 = problems[order[lo]];
         const int bw = q0.bw, K = 2 * bw + 1, KP = kp_for(bw), ncb = 48 / KP;
-        const bool narrow = q0.n_chans <= 64;
+        const int width = width_class(q0.n_chans);
         int max_trig = 0, max_groups = 0, max_split = 0, max_p = 0;
         bool any_split = false;
         for (int slot = lo; slot < hi; ++slot) {
@@ -1421,7 +1432,9 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         const unsigned nz = static_cast<unsigned>(hi - lo);
         const GangProblem *sub = d_tab + lo;
         hipLaunchKernelGGL(fit_trig_stacked_gang, dim3(max_trig, max_groups, nz), dim3(64 * ncb), 0, s, sub, bw, KP, exact);
-        if (narrow)
+        if (width == 0)
+            hipLaunchKernelGGL((fit_accum_mfma_gang<1, 1>), dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
+        else if (width == 1)
             hipLaunchKernelGGL(fit_accum_mfma_gang<1>, dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
         else
             hipLaunchKernelGGL(fit_accum_mfma_gang<4>, dim3(max_split, max_groups, nz), dim3(256), 0, s, sub, KP);
