@@ -830,3 +830,27 @@ def test_find_period_on_degenerate_recordings_behaves_like_the_reference(case):
         assert got[1] == want[1]
     else:
         assert abs(got[1] - want[1]) <= PERIOD_RTOL * want[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["gang", "streams", "wide"])
+def test_batched_forms_agree_with_single_searches(monkeypatch, form):
+    """``parrm_fit_errors_multi`` has two forms: gang launches (one launch per kernel, blockIdx.z picks the problem)
+    and one side stream per problem -- the fallback for problems the gang form cannot take (here forced by the
+    environment, and reached for real by a recording of more than 256 channels).  Both must give every search the
+    period its own ``find_period()`` gives, bit for bit."""
+    from pyparrm_amd import find_period_batched
+
+    if form == "streams":
+        monkeypatch.setenv("PARRM_FIT_MULTI_STREAMS", "1")
+    chans = (1, 3, 20, 70) if form != "wide" else (2, 260)
+    recs = [synth_recording_exact(c, 30_000 + 1000 * k, 1000.0 / 130.0 * (1 + 1e-4 * (k + 1)), seed=60 + k)
+            for k, c in enumerate(chans)]
+    singles = []
+    for x in recs:
+        p = PARRM(x, 1000, 130, verbose=False)
+        p.find_period(random_seed=11)
+        singles.append(p.period)
+    batch = [PARRM(x, 1000, 130, verbose=False) for x in recs]
+    find_period_batched(batch, random_seed=11)
+    assert [p.period for p in batch] == singles
