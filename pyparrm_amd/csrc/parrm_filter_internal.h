@@ -47,7 +47,11 @@ __device__ inline void emit(const FilterArgs &a, int64_t c, int64_t n, double xc
         y = xc - s * a.inv_taps;
     } else {
         const int v = valid_taps(a, n);
-        y = v > 0 ? xc - s / static_cast<double>(v) : 0.0;
+        // no tap inside the recording: 0 (the reference's 0/0 -> NaN -> 0).  The recurrence kernels keep a poisoned
+        // running sum VISIBLE there (s * 0 is NaN for a non-finite s, 0 otherwise): with a one-sided filter the last
+        // outputs of a recording have no valid tap, and they are where the repair pass looks for the poison
+        // (scripts/fuzz_filter_r2.py, seed 32 case 138)
+        y = v > 0 ? xc - s / static_cast<double>(v) : (ZERO_NONFINITE ? 0.0 : s * 0.0);
     }
     if (ZERO_NONFINITE && !isfinite(y)) y = 0.0;  // parrm.py:869
     static_cast<TO *>(a.y)[c * a.ldy + (n - a.out_first)] = static_cast<TO>(y);

@@ -854,3 +854,35 @@ def test_batched_forms_agree_with_single_searches(monkeypatch, form):
     batch = [PARRM(x, 1000, 130, verbose=False) for x in recs]
     find_period_batched(batch, random_seed=11)
     assert [p.period for p in batch] == singles
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direction", ["past", "future"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_nonfinite_sample_near_an_end_whose_outputs_have_no_valid_tap(monkeypatch, direction, dtype):
+    """With a one-sided filter the outputs at one end of the recording have no tap inside it (they are 0 whatever the
+    running sums hold) -- and the end of the last stretch is where the repair pass looks for a poisoned sum.  The
+    recurrence kernels keep the poison visible there (scripts/fuzz_filter_r2.py, seed 32 case 138: NaN outputs
+    survived, rows before the sample's reach included)."""
+    monkeypatch.setenv("PARRM_STRETCH_SAMPLES", "60000")
+    period = 481.82980394479245
+    filt = orc.generate_filter(period, 650, 17, direction, 9.636596078895849)
+    n = 5000
+    x = np.random.default_rng(2).standard_normal((2, n)).astype(dtype)
+    x[0, 3764 if direction == "past" else 1236] = np.nan
+    ref = orc.filter_data_direct(x.astype(np.float64), filt)
+    plan = _hip.FilterPlan(filt)
+    info = plan.info
+    kernels = [_hip.KERNEL_GATHER]
+    if info.stride > 0:
+        kernels.append(_hip.KERNEL_STRIDE)
+    if info.phase_groups > 0:
+        kernels.append(_hip.KERNEL_PHASE)
+    assert len(kernels) > 1
+    d_x = torch.from_numpy(x).cuda()
+    for kern in kernels:
+        plan.set_kernel(kern)
+        y = plan.apply(d_x).cpu().numpy()
+        assert np.all(np.isfinite(y)), kern
+        assert np.array_equal(y == 0, ref == 0), kern
+        assert np.abs(y - ref).max() <= (1e-10 if dtype == np.float64 else 1e-5) * np.abs(ref).max(), kern
