@@ -158,10 +158,13 @@ def main():
                 counts["launches"] += 1
                 worst[key] = max(worst[key], check(f"resident kernel {kern} out {out_dtype}", y, ref, tol, desc))
                 if spec["bad"]:  # zeros exactly where the closed form has them
-                    z_ref, z_got = ref == 0.0, y == 0.0
-                    if not np.array_equal(z_ref, z_got):
+                    # (a clean output that happens to be exactly 0 in one evaluation order and 1e-17 in the other is not a
+                    # pattern difference: seed 136 case 8, three taps whose mean equals the sample)
+                    scale = max(float(np.abs(ref).max()), 1e-300)
+                    differs = ((ref == 0.0) != (y == 0.0)) & (np.maximum(np.abs(ref), np.abs(y.astype(np.float64))) > 1e-12 * scale)
+                    if differs.any():
                         print(f"FAIL zero pattern kernel {kern} out {out_dtype}: {desc}: "
-                              f"{int((z_ref != z_got).sum())} outputs differ")
+                              f"{int(differs.sum())} outputs differ")
                         sys.exit(1)
         plan.set_kernel(_hip.KERNEL_AUTO)
         tol = 1e-5 if f32 else 1e-10
