@@ -161,7 +161,7 @@ def main():
                     # (a clean output that happens to be exactly 0 in one evaluation order and 1e-17 in the other is not a
                     # pattern difference: seed 136 case 8, three taps whose mean equals the sample)
                     scale = max(float(np.abs(ref).max()), 1e-300)
-                    differs = ((ref == 0.0) != (y == 0.0)) & (np.maximum(np.abs(ref), np.abs(y.astype(np.float64))) > 1e-12 * scale)
+                    differs = ((ref == 0.0) != (y == 0.0)) & (np.maximum(np.abs(ref), np.abs(y.astype(np.float64))) > tol * scale)
                     if differs.any():
                         print(f"FAIL zero pattern kernel {kern} out {out_dtype}: {desc}: "
                               f"{int(differs.sum())} outputs differ")
