@@ -343,3 +343,38 @@ def test_online_filter_reach_and_latency_rules(golden):
     q = PARRM(_data(), FS, FA, verbose=False)
     with pytest.raises(ValueError, match="The filter has not yet been created"):
         q.online()
+
+
+def test_create_filter_random_parameters_match_the_oracle():
+    """300 random (period, recording length, half-width, omitted samples, direction, period half-width) draws: the
+    façade's ``create_filter`` (host NumPy, parrm.py:739-833) and the oracle's restatement -- written separately, the
+    oracle pinned bit for bit by the reference's fixtures -- give the same half-width and the same taps, or raise the
+    same RuntimeError."""
+    from oracle import parrm_oracle as orc
+
+    rng = np.random.default_rng(2024)
+    checked = raised = 0
+    for _ in range(300):
+        period = float(rng.choice([1.3311, 2.024, 7.7424, 13.0, 64.3, 169.2358, 333.3])) * (1 + rng.uniform(-1e-3, 1e-3))
+        n_samples = int(rng.choice([40, 400, 6001, 60000]))
+        limit = (n_samples - 1) // 2
+        omit = int(rng.integers(0, max(1, min(limit - 1, 40))))
+        explicit_hw = rng.random() < 0.6
+        hw = int(rng.integers(omit + 1, limit + 1)) if explicit_hw and limit > omit + 1 else None
+        direction = str(rng.choice(["both", "past", "future"]))
+        phw = float(rng.uniform(1e-3, 1.0) * period) if rng.random() < 0.6 else None
+        p = _with_period(np.zeros((1, n_samples)), period, 22000, 130)
+        phw_eff = period / 50 if phw is None else phw
+        want_hw = hw if hw is not None else orc.default_filter_half_width(n_samples, period, omit, phw_eff)
+        try:
+            want = orc.generate_filter(period, want_hw, omit, direction, phw_eff)
+        except RuntimeError:
+            with pytest.raises(RuntimeError, match="A suitable filter cannot be created"):
+                p.create_filter(hw, omit, direction, phw)
+            raised += 1
+            continue
+        p.create_filter(hw, omit, direction, phw)
+        assert p._filter_half_width == want_hw
+        np.testing.assert_array_equal(p.filter, want)
+        checked += 1
+    assert checked > 200 and raised > 0
