@@ -454,6 +454,7 @@ def unpin_host(array: np.ndarray) -> None:
     check(lib().parrm_host_unpin(array.ctypes.data_as(C.c_void_p)), "parrm_host_unpin")
 
 
+_NO_LEAN_CALLS = bool(os.environ.get("PARRM_NO_LEAN_CALLS"))  # A/B knob: the generic wrapper for every call
 _INDEX_STAGING: dict = {}
 
 
@@ -521,10 +522,49 @@ class FitWorkspace:
 
     MAX_BYTES = 12 << 30
 
+    #: candidates per call the lean optimiser-step path takes (``small_batch``)
+    LEAN_MAX = 64
+
     def __init__(self):
         self._buf = None
         self._sizes = {}
         self._h_per = self._h_err = self._d_per = self._d_err = None
+        self._lean = None  # (y, idx, bandwidth) and everything derived from them, see small_batch
+
+    def small_batch(self, torch, y, idx, periods: np.ndarray, bandwidth: int, lambda_: float):
+        """One optimiser step (<= ``LEAN_MAX`` abscissae) through ``parrm_fit_errors_host`` with everything that
+        does not change between the steps of a stage -- pointers, strides, sizes, the staging arrays' addresses --
+        prepared once: the generic wrapper costs ~25 us of Python per call, a Nelder-Mead phase makes ~80 of them."""
+        lean = self._lean
+        if lean is None or lean[0] is not y or lean[1] is not idx or lean[2] != bandwidth:
+            n_idx, n_chans = y.shape
+            h_per, h_out = np.empty(self.LEAN_MAX, dtype=np.float64), np.empty(self.LEAN_MAX, dtype=np.float64)
+            raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+            lean = [y, idx, bandwidth, y.data_ptr(), y.stride(0), idx.data_ptr(), int(n_idx), int(n_chans), y.device,
+                    y.device.index, h_per, h_out, h_per.ctypes.data, h_out.ctypes.data, {}, raw,
+                    lib().parrm_fit_errors_host]
+            self._lean = lean
+        (_, _, _, y_ptr, ldy, idx_ptr, n_idx, n_chans, device, dev_index, h_per, h_out, per_addr, out_addr, sizes, raw,
+         call) = lean
+        n_per = periods.shape[0]
+        h_per[:n_per] = periods
+        nbytes = sizes.get(n_per)
+        if nbytes is None:
+            nbytes = sizes[n_per] = self.nbytes(n_idx, n_chans, n_per, bandwidth) + 16 * n_per
+        buf = self._buf
+        if buf is None or buf.numel() * 8 < nbytes or buf.device != device:
+            buf = self.get(nbytes, device)
+        if dev_index != torch.cuda.current_device():
+            with torch.cuda.device(device):
+                rc = call(y_ptr, ldy, idx_ptr, n_idx, n_chans, per_addr, n_per, bandwidth, lambda_, out_addr,
+                          buf.data_ptr(), nbytes, _stream_ptr(torch))
+        else:
+            stream = int(raw(dev_index)) if raw is not None else _stream_ptr(torch)
+            rc = call(y_ptr, ldy, idx_ptr, n_idx, n_chans, per_addr, n_per, bandwidth, lambda_, out_addr,
+                      buf.data_ptr(), nbytes, stream)
+        if rc:
+            check(rc, "parrm_fit_errors_host")
+        return h_out[:n_per].copy()
 
     def get(self, nbytes: int, device):
         torch = require_gpu()
@@ -561,12 +601,14 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
     (``parrm_fit_errors_slice``).
     """
     torch = require_gpu()
-    L = lib()
     periods = np.ascontiguousarray(np.asarray(periods, dtype=np.float64).reshape(-1))
-    n_idx, n_chans = y.shape
     n_per = periods.shape[0]
     if n_per == 0:
         return np.empty(0, dtype=np.float64)
+    if workspace is not None and n_per <= FitWorkspace.LEAN_MAX and not grid_periods and not _NO_LEAN_CALLS:
+        return workspace.small_batch(torch, y, idx, periods, int(bandwidth), float(lambda_))
+    L = lib()
+    n_idx, n_chans = y.shape
     ws = workspace or FitWorkspace()
     if ws.nbytes(n_idx, n_chans, 1, bandwidth) == 0:
         raise HipLibraryError("parrm_fit_workspace_bytes rejected the problem shape")
