@@ -312,7 +312,7 @@ template <int NW, int CT>
 __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy, const double *Ws, int n_pad, int n_idx,
                                                     int n_chans, int n_periods, int kpc, int nsplit, double *part,
                                                     const Blk blk) {
-    static_assert(CT == 4 || (CT == 1 && NW == 1), "CT = 1: the one-wave form for <= 16 channels");
+    static_assert(CT == 4 || ((CT == 1 || CT == 2) && NW == 1), "CT = 1, 2: one-wave forms for <= 16 / <= 32 channels");
     constexpr int KS = 48, D = 4, NG = NW == 4 ? 1 : 3;  // Gram row-tiles per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = NW == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -330,7 +330,7 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         static_cast<int>((static_cast<int64_t>(n_idx) * ldy - static_cast<int64_t>(zb) * kYCols) * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(Ws) + static_cast<int64_t>(pb) * n_pad * KS, 0, n_pad * KS * 8, 0x00020000);
-    const int col0 = CT == 4 ? 64 * wv + 4 * c : c;    // first of this lane's four data columns (CT = 1: its only one)
+    const int col0 = CT == 4 ? 64 * wv + 4 * c : CT * c;  // first of this lane's CT adjacent data columns
     // a quad may straddle n_chans: its extra columns come from the row's padding (or, with a tight
     // ldy, from the next row / the zero tail) and land in result columns that nothing reads
     const bool col_ok = zb * kYCols + col0 < n_chans;
@@ -360,6 +360,10 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
             ry[d][2] = __builtin_bit_cast(double, u2_t{y23.x, y23.y});
             ry[d][3] = __builtin_bit_cast(double, u2_t{y23.z, y23.w});
+        } else if constexpr (CT == 2) {
+            const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
+            ry[d][0] = __builtin_bit_cast(double, u2_t{y01.x, y01.y});
+            ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
         } else {
             ry[d][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_y, vy, 0, 0));
         }
@@ -1206,9 +1210,12 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
                            bw, g.KP, exact_trig, wmat);
     PARRM_HIP_CHECK(hipGetLastError());
     const dim3 grid(g.nsplit, groups, g.nz);
-    const bool narrow16 = C <= 16 && !getenv("PARRM_FIT_NO_NARROW16");
-    if (use_mfma && narrow16)
+    const bool narrow_ok = !getenv("PARRM_FIT_NO_NARROW16");  // (A/B knob: the 64-column form for every C <= 64)
+    if (use_mfma && C <= 16 && narrow_ok)
         hipLaunchKernelGGL((fit_accum_mfma_kernel<1, 1>), grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
+                           part);
+    else if (use_mfma && C <= 32 && narrow_ok)
+        hipLaunchKernelGGL((fit_accum_mfma_kernel<1, 2>), grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
                            part);
     else if (use_mfma && C <= 64)
         hipLaunchKernelGGL(fit_accum_mfma_kernel<1>, grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
@@ -1365,7 +1372,7 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
     std::vector<int> order(n_problems);
     for (int p = 0; p < n_problems; ++p) order[p] = p;
     const bool no16 = getenv("PARRM_FIT_NO_NARROW16") != nullptr;
-    auto width_class = [&](int64_t c) { return c <= 16 && !no16 ? 0 : (c <= 64 ? 1 : 2); };
+    auto width_class = [&](int64_t c) { return c <= 16 && !no16 ? 0 : (c <= 32 && !no16 ? 3 : (c <= 64 ? 1 : 2)); };
     auto bucket = [](int64_t v) {
         int b = 0;
         while ((int64_t{1} << b) < v) ++b;
@@ -1434,6 +1441,8 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         hipLaunchKernelGGL(fit_trig_stacked_gang, dim3(max_trig, max_groups, nz), dim3(64 * ncb), 0, s, sub, bw, KP, exact);
         if (width == 0)
             hipLaunchKernelGGL((fit_accum_mfma_gang<1, 1>), dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
+        else if (width == 3)
+            hipLaunchKernelGGL((fit_accum_mfma_gang<1, 2>), dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
         else if (width == 1)
             hipLaunchKernelGGL(fit_accum_mfma_gang<1>, dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
         else
