@@ -312,10 +312,13 @@ template <int NW, int CT>
 __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy, const double *Ws, int n_pad, int n_idx,
                                                     int n_chans, int n_periods, int kpc, int nsplit, double *part,
                                                     const Blk blk) {
+    static_assert(NW == 1 || NW == 2 || NW == 4, "one wave (<= 64 channels), two (<= 128) or four (256 per block)");
     static_assert(CT == 4 || ((CT == 1 || CT == 2) && NW == 1), "CT = 1, 2: one-wave forms for <= 16 / <= 32 channels");
-    constexpr int KS = 48, D = 4, NG = NW == 4 ? 1 : 3;  // Gram row-tiles per wave
+    // Gram row-tiles per wave: NW = 4: waves 0-2 one each (wave 3 repeats tile 2, not stored); NW = 2: wave 0 tiles
+    // 0 and 1, wave 1 tile 2 twice (the second not stored: straight-line code for both waves); NW = 1: all three
+    constexpr int KS = 48, D = 4, NG = NW == 4 ? 1 : (NW == 2 ? 2 : 3);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = NW == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, sj = lane >> 4;
     const int sl = blk.x, pb = blk.y, zb = blk.z, nz = blk.nz;
     const int ncb = KS / kpc;
@@ -398,6 +401,13 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct)
                     gacc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, a[ct], gacc[0][ct], 0, 0, 0);
+            } else if constexpr (NW == 2) {
+                const double aw0 = wv == 0 ? a[0] : a[2], aw1 = wv == 0 ? a[1] : a[2];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    gacc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw0, a[ct], gacc[0][ct], 0, 0, 0);
+                    gacc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw1, a[ct], gacc[1][ct], 0, 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int gr = 0; gr < 3; ++gr)
@@ -432,7 +442,8 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     if (wv < 3) {
 #pragma unroll
         for (int gr = 0; gr < NG; ++gr) {
-            const int rt = NW == 4 ? wv : gr;
+            if (NW == 2 && wv == 1 && gr == 1) continue;  // (the repeated tile)
+            const int rt = NW == 4 ? wv : (NW == 2 ? (wv == 0 ? gr : 2) : gr);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int r = 16 * rt + sj + 4 * v;
@@ -1219,6 +1230,9 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
                            part);
     else if (use_mfma && C <= 64)
         hipLaunchKernelGGL(fit_accum_mfma_kernel<1>, grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
+                           part);
+    else if (use_mfma && C <= 128 && g.nz == 1 && !getenv("PARRM_FIT_NO_TWO_WAVES"))
+        hipLaunchKernelGGL(fit_accum_mfma_kernel<2>, grid, dim3(128), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
                            part);
     else if (use_mfma)
         hipLaunchKernelGGL(fit_accum_mfma_kernel<4>, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
