@@ -886,3 +886,26 @@ def test_nonfinite_sample_near_an_end_whose_outputs_have_no_valid_tap(monkeypatc
         assert np.all(np.isfinite(y)), kern
         assert np.array_equal(y == 0, ref == 0), kern
         assert np.abs(y - ref).max() <= (1e-10 if dtype == np.float64 else 1e-5) * np.abs(ref).max(), kern
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_chans,knob", [(1, "PARRM_FIT_NO_NARROW16"), (13, "PARRM_FIT_NO_NARROW16"), (24, "PARRM_FIT_NO_NARROW16"),
+                                          (32, "PARRM_FIT_NO_NARROW16"), (65, "PARRM_FIT_NO_TWO_WAVES"), (128, "PARRM_FIT_NO_TWO_WAVES")])
+def test_gram_kernel_forms_return_the_same_bits(monkeypatch, n_chans, knob):
+    """The Gram kernel has a form per channel-count class (16 / 32 / 64 columns on one wave, 128 on two waves, 256 on
+    four).  An MFMA output element does not depend on the other columns and every form is planned with the same
+    sample split, so a recording gets bit for bit the errors the wider form would give it."""
+    g = torch.Generator(device="cuda").manual_seed(n_chans)
+    ws = _hip.FitWorkspace()
+    for n_per, n, bw in ((130, 5001, 5), (7, 24963, 20), (40, 10001, 10)):
+        y = torch.randn((n, (n_chans + 3) // 4 * 4), generator=g, device="cuda", dtype=torch.float64).clamp_(-3, 3)[:, :n_chans]
+        idx = torch.sort(torch.randperm(60000, device="cuda", generator=g)[:n]).values.to(torch.int64)
+        periods = 169.2 * (1 + np.linspace(-1e-2, 1e-2, n_per))
+        narrow = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+        monkeypatch.setenv(knob, "1")
+        wide = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+        monkeypatch.delenv(knob)
+        assert np.array_equal(narrow, wide), (n_per, n, bw)
+        rows = np.ascontiguousarray(y.cpu().numpy().T)
+        ref = np.array([orc.fit_error_gathered(p, rows, n_chans, idx.cpu().numpy(), bw, 1.0) for p in periods[:3]])
+        np.testing.assert_allclose(narrow[:3], ref, rtol=1e-9)
