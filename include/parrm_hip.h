@@ -145,6 +145,16 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
                       int y_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
                       int64_t ldy, int64_t chunk_samples);
 
+/* The filter kernel of float64 recordings is GENERATED per filter geometry (tap offsets as instruction
+ * immediates; parrm.py:861-869 is the arithmetic, :803-833 the filter it is specialised for): hipRTC at the
+ * first launch of at least 2^25 samples, code objects cached under $PARRM_KERNEL_CACHE (default
+ * ~/.cache/pyparrm_amd) and looked up first in <library dir>/kernels/.  This build-time helper needs no GPU:
+ * it generates the kernel for a filter array and writes <out_dir>/comb_<hash>.hsaco (and its source, whose
+ * path is returned in source_path when that is not NULL).  `stride` 0 = the stride a plan would choose.
+ * PARRM_ERR_INVALID when the generated form does not take this filter (such filters run the generic kernels). */
+int parrm_filter_comb_precompile(const double *h_filter, int64_t filter_len, int64_t stride,
+                                 const char *out_dir, char *source_path, size_t source_path_len);
+
 /* ------------------------------------------------------------------------------------
  * find_period, statistics pass  (parrm.py:272-280, `_standardise_data`)
  *

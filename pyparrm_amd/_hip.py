@@ -33,6 +33,7 @@ SYMBOLS = (
     "parrm_filter_apply_window",
     "parrm_filter_apply_block",
     "parrm_filter_host",
+    "parrm_filter_comb_precompile",
     "parrm_host_pin",
     "parrm_host_unpin",
     "parrm_absdiff_workspace_bytes",

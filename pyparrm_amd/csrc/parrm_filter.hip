@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "parrm_filter_internal.h"
@@ -294,6 +295,31 @@ __global__ void __launch_bounds__(256) filter_combine_kernel(FilterArgs a, const
 template <typename TI, typename TO>
 int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStream_t stream);
 
+// The generated kernel (parrm_filter_comb.hip) for this launch, or nullptr: float64 recordings, guarded phase
+// plans with q in [96, 256].  PARRM_COMB=0 turns it off, PARRM_COMB=force takes it for any size; otherwise a
+// launch must be large enough (2^25 samples) to be worth a possible hipRTC compile (seconds, once per filter
+// geometry: code objects are cached on disk).  A failure to generate, compile or load is remembered and the
+// launch falls back to filter_phase_kernel -- same results within the parity bar, never an error.
+std::mutex g_comb_mutex;
+const CombKernel *comb_for_launch(const parrm_filter_plan *p, const FilterArgs &a) {
+    const char *env = getenv("PARRM_COMB");
+    if (env && env[0] == '0') return nullptr;
+    const bool force = env && env[0] == 'f';
+    if (!force && a.plan_chans * a.out_len < (int64_t{1} << 25)) return nullptr;
+    if (p->phase.n_groups == 0 || p->phase.wrap || p->tap_mask.empty()) return nullptr;
+    std::lock_guard<std::mutex> lock(g_comb_mutex);
+    if (p->comb_state == 0) {
+        p->comb = comb_generate(p->tap_mask, p->hw, p->phase.q);
+        p->comb_state = -1;
+        if (p->comb) {
+            if (comb_load(p->comb)) p->comb_state = 1;
+            else if (getenv("PARRM_COMB_VERBOSE")) fprintf(stderr, "parrm: generated filter kernel unavailable: %s\n", comb_error(p->comb));
+        }
+    }
+    if (p->comb_state != 1 || !comb_accepts(p->comb, a)) return nullptr;
+    return p->comb;
+}
+
 // A recurrence launch is followed by the repair pass (parrm_filter_internal.h: non-finite inputs).
 template <typename TI, typename TO>
 int launch_segmented(const parrm_filter_plan *p, FilterArgs a, hipStream_t stream) {
@@ -357,6 +383,9 @@ template <typename TI, typename TO>
 int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStream_t stream) {
     FilterArgs &a = *args;
     if (kernel == PARRM_KERNEL_PHASE) {
+        if constexpr (sizeof(TI) == 8 && sizeof(TO) == 8) {
+            if (const CombKernel *ck = comb_for_launch(p, a)) return launch_comb(ck, args, stream);
+        }
         // the three-residues-per-lane form where the plan has one (PARRM_PHASE3=0 at plan time turns it off)
         if (p->phase3.n_groups > 0) return launch_phase3<TI, TO>(p->phase3, p->d_phase3_tab, args, stream);
         return launch_phase<TI, TO>(p, args, stream);
@@ -581,6 +610,7 @@ static int build_plan(const std::vector<int8_t> &tap, int64_t hw, bool allow_seg
     p->d_phase_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb);
     p->d_phase3_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb + pb);
     if (allow_segments && p->phase.n_groups == 0 && p->q == 0) build_segments(tap, hw, p);
+    if (allow_segments) p->tap_mask = tap;  // (sub-plans of a segmented filter never take the generated kernel)
     *plan = p;
     return PARRM_OK;
 }
@@ -589,6 +619,7 @@ int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
     if (!plan) return PARRM_OK;
     if (plan->d_weights) (void)hipFree(plan->d_weights);  // the one allocation (weights | tables | phase table)
     for (parrm_filter_plan *sub : plan->segments) (void)parrm_filter_plan_destroy(sub);
+    parrm_filter::comb_destroy(plan->comb);
     delete plan;
     return PARRM_OK;
 }

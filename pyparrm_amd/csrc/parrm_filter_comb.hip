@@ -1,0 +1,771 @@
+// filter_data, per-filter GENERATED kernel ("comb" kernel) -- parrm.py:861-869 for float64 recordings.
+//
+// Same recurrence as the phase-major kernel (parrm_filter_phase_impl.h),
+//
+//     S(n+q) = S(n) + sum_u d_q(u) xz[n-u],        d_q(u) = tap(u+q) - tap(u),     u = a*q + b, |b| <= HB,
+//
+// but the tap geometry is COMPILE-TIME data of a kernel generated for the one filter (hipRTC at first use,
+// code objects cached on disk and shipped in-tree for the BASELINE geometry), and the work is cut differently:
+//
+//   * Stage A (tap sums).  A lane owns C CONSECUTIVE residues of one row (16 lanes x C = one row of q
+//     residues; C = 11 for q = 169), a wave four rows.  A delta tap is C ds_read_b64 off ONE lane base with
+//     immediate offsets (the ring slot of row m - a is a compile-time constant because the loop is unrolled
+//     over the ring period: no per-tap address arithmetic, no table, no scalar loads), and a tooth that
+//     enters or leaves as w adjacent taps is a SLIDING sum over C + w - 1 reads:
+//     T_0 = e_0 + .. + e_{w-1},  T_i = T_{i-1} + e_{i+w-1} - e_{i-1}.  BASELINE geometry (28 delta taps =
+//     14 single taps + two 7-wide teeth): 17.1 LDS reads and 20.7 float64 adds per output instead of 28 + 28
+//     (+ 17 address adds + table traffic) in the phase-major kernel.
+//   * Stage B (outputs).  Thread = residue (coalesced 8-byte stores as before) walks the NR rows of the
+//     iteration: y = x - S / n_taps, S += Delta.  The Delta values change hands through an LDS buffer; S stays
+//     in a register for the whole stretch, so there is no chain between row groups at all.
+//   * Rows land in the LDS ring by LDS-DMA (buffer_load_dwordx4 ... lds), two iterations ahead: no staging
+//     registers, no ds_write traffic, 16-byte coalesced requests.  Ring layout: row-major [slot][PITCH] with HB
+//     halo columns each side (loaded, not mirrored); PITCH = 4 mod 8 and the two rows of a half-wave four
+//     slots apart make every ds_read_b64 conflict-free.
+//   * Rows that touch the ends of the recording / of the addressable window are filled and emitted by a
+//     generic slow path (zero padding, divisor from the cumulative tap counts), everything else is
+//     straight-line code.
+//
+// Non-finite samples: as for every recurrence kernel, results are stored as computed and filter_repair_kernel
+// runs behind the launch (parrm_filter_internal.h).
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "parrm_filter_internal.h"
+
+namespace parrm_filter {
+
+namespace {
+
+constexpr int kNR = 16;       // rows per iteration (4 waves x 4 rows)
+constexpr int kThreads = 256;
+constexpr int kLdsLimit = 160 * 1024;
+
+struct Unit {  // one delta element: `width` adjacent taps of one sign in row m - a, offsets b_lo .. b_lo + width - 1
+    int a, b_lo, width, sign;
+};
+struct Run {   // full-tap run for the per-stretch initialisation
+    int a, b_lo, b_hi;
+};
+
+struct Geom {
+    int q = 0, c = 0, hb = 0, ncol = 0, pitch = 0, ms = 0, a_lo = 0, a_hi = 0;
+    int pb = 0, dpb = 0, ring_bytes = 0, lds_total = 0, hs = 0, period = 0;
+    int n_taps = 0;
+    std::vector<Unit> units;
+    std::vector<Run> runs;
+};
+
+inline int floordiv_round(int64_t u, int64_t q) {  // nearest multiple
+    return static_cast<int>(std::floor(static_cast<double>(u) / static_cast<double>(q) + 0.5));
+}
+
+// Geometry for a tap mask and a stride; false when this kernel cannot take the filter.
+bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
+    auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
+    if (q < 96 || q > 256) return false;
+    g->q = static_cast<int>(q);
+    int guard = 0;
+    g->a_lo = 1 << 30;
+    g->a_hi = -(1 << 30);
+    // delta taps, ascending in u
+    std::vector<std::pair<int64_t, int>> delta;
+    for (int64_t u = -hw - q; u <= hw; ++u) {
+        const int d = tap_at(u + q) - tap_at(u);
+        if (d == 0) continue;
+        delta.push_back({u, d});
+        const int a = floordiv_round(u, q);
+        const int b = static_cast<int>(u - static_cast<int64_t>(a) * q);
+        guard = std::max(guard, std::abs(b));
+        g->a_lo = std::min(g->a_lo, a);
+        g->a_hi = std::max(g->a_hi, a);
+    }
+    if (delta.empty() || delta.size() > 96) return false;
+    g->n_taps = 0;
+    for (int64_t w = -hw; w <= hw; ++w) {
+        if (!tap_at(w)) continue;
+        ++g->n_taps;
+        const int a = floordiv_round(w, q);
+        guard = std::max(guard, std::abs(static_cast<int>(w - static_cast<int64_t>(a) * q)));
+        g->a_lo = std::min(g->a_lo, a);  // the initialisation reads row -a of the prologue fill
+        g->a_hi = std::max(g->a_hi, a);
+    }
+    if (guard > 12) return false;
+    g->hb = guard;
+    // units: maximal groups of adjacent offsets with one sign inside one row
+    for (size_t i = 0; i < delta.size();) {
+        const int a = floordiv_round(delta[i].first, q);
+        size_t j = i;
+        while (j + 1 < delta.size() && delta[j + 1].first == delta[j].first + 1 && delta[j + 1].second == delta[i].second &&
+               floordiv_round(delta[j + 1].first, q) == a)
+            ++j;
+        Unit u;
+        u.a = a;
+        u.b_lo = static_cast<int>(delta[i].first - static_cast<int64_t>(a) * q);
+        u.width = static_cast<int>(j - i + 1);
+        u.sign = delta[i].second;
+        g->units.push_back(u);
+        i = j + 1;
+    }
+    for (int64_t w = -hw; w <= hw;) {
+        if (!tap_at(w)) {
+            ++w;
+            continue;
+        }
+        const int a = floordiv_round(w, q);
+        int64_t e = w;
+        while (e + 1 <= hw && tap_at(e + 1) && floordiv_round(e + 1, q) == a) ++e;
+        g->runs.push_back({a, static_cast<int>(w - static_cast<int64_t>(a) * q), static_cast<int>(e - static_cast<int64_t>(a) * q)});
+        w = e + 1;
+    }
+    // C residues per lane, 16 lanes per row; C odd keeps a lane stride of C*8 bytes conflict-free
+    int c = static_cast<int>((q + 15) / 16);
+    if ((c & 1) == 0) ++c;
+    if (c > 17) return false;
+    g->c = c;
+    g->ncol = 2 * g->hb + 16 * c;
+    int pitch = g->ncol;
+    while ((pitch & 7) != 4) ++pitch;  // 4 mod 8: partner rows four slots apart sit 32 banks apart; 16-byte rows
+    g->pitch = pitch;
+    g->pb = pitch * 8;
+    g->dpb = 16 * c * 8;
+    // live rows when the rows of iteration k+2 are requested: [16k - max(16, a_hi), 16k + 48 - a_lo)
+    const int live = std::max(kNR, g->a_hi) + 3 * kNR - g->a_lo;
+    g->ms = (live + kNR - 1) / kNR * kNR;
+    g->period = g->ms / kNR;
+    g->hs = g->ms / 2;
+    g->ring_bytes = g->ms * g->pb;
+    g->lds_total = g->ring_bytes + kNR * g->dpb;
+    if (g->lds_total > kLdsLimit) return false;
+    if (g->hs * g->pb + g->pb > 65000) return false;     // immediates of ds_read are 16 bits
+    if (g->a_hi - g->a_lo + 2 * kNR > g->ms) return false;  // prologue fill must not wrap
+    if (g->pb / 16 > 128 || g->pb / 16 <= 64) return false;  // two DMA instructions per row
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- source
+struct Read {
+    std::string base;
+    int imm;
+};
+
+class Emitter {
+   public:
+    explicit Emitter(const Geom &g, int batch) : g_(g), batch_(batch) {}
+
+    // (base register, immediate) of element `col` of ring row m - a for lane row r, at ring phase km
+    Read tap_address(int km, int a, int col, std::vector<int> *thetas) const {
+        int slot0 = (kNR * km + g_.a_hi - a) % g_.ms;
+        if (slot0 < 0) slot0 += g_.ms;
+        Read r;
+        if (slot0 + kNR - 1 < g_.ms) {
+            if (slot0 < g_.hs) {
+                r.base = "B0";
+                r.imm = slot0 * g_.pb + col * 8;
+            } else {
+                r.base = "B1";
+                r.imm = (slot0 - g_.hs) * g_.pb + col * 8;
+            }
+        } else {
+            const int theta = g_.ms - slot0;
+            if (std::find(thetas->begin(), thetas->end(), theta) == thetas->end()) thetas->push_back(theta);
+            r.base = "B1w" + std::to_string(theta);
+            r.imm = (slot0 - g_.hs) * g_.pb + col * 8;
+        }
+        return r;
+    }
+
+    // Pipelined LDS reads: statement j issues batch j and waits, with a counted lgkmcnt, for batch j - 1
+    // (LDS operations return in order); the arithmetic on a batch is emitted behind the statement that waits
+    // for it, fenced by a sched_barrier (the compiler does not know the results are asynchronous).
+    //   reads[i]        : where value e<prefix><i> comes from
+    //   compute[i]      : statements that may run once read i (and every earlier one) is back
+    void emit_pipeline(std::ostringstream &o, const std::string &prefix, const std::vector<Read> &reads,
+                       const std::vector<std::string> &compute) const {
+        const int n = static_cast<int>(reads.size());
+        o << "        double";
+        for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << prefix << i;
+        o << ";\n";
+        const int nb = (n + batch_ - 1) / batch_;
+        for (int j = 0; j <= nb; ++j) {
+            if (j < nb) {
+                const int lo = j * batch_, hi = std::min(n, lo + batch_);
+                // distinct bases of this batch
+                std::vector<std::string> bases;
+                for (int i = lo; i < hi; ++i)
+                    if (std::find(bases.begin(), bases.end(), reads[i].base) == bases.end()) bases.push_back(reads[i].base);
+                o << "        asm volatile(";
+                for (int i = lo; i < hi; ++i) {
+                    const int bi = static_cast<int>(std::find(bases.begin(), bases.end(), reads[i].base) - bases.begin());
+                    o << "\"ds_read_b64 %" << (i - lo) << ", %" << (hi - lo + bi) << " offset:" << reads[i].imm << "\\n\\t\"\n                     ";
+                }
+                if (j > 0) o << "\"s_waitcnt lgkmcnt(" << (hi - lo) << ")\"";
+                else o << "\"\"";
+                o << "\n                     :";
+                for (int i = lo; i < hi; ++i) o << (i > lo ? ", " : " ") << "\"=&v\"(" << prefix << i << ")";
+                o << "\n                     :";
+                for (size_t b = 0; b < bases.size(); ++b) o << (b ? ", " : " ") << "\"v\"(" << bases[b] << ")";
+                o << ");\n";
+            } else {
+                o << "        asm volatile(\"s_waitcnt lgkmcnt(0)\");\n";
+            }
+            if (j > 0) {
+                o << "        __builtin_amdgcn_sched_barrier(0);\n";
+                const int lo = (j - 1) * batch_, hi = std::min(n, lo + batch_);
+                for (int i = lo; i < hi; ++i)
+                    if (!compute[i].empty()) o << compute[i];
+            }
+        }
+    }
+
+    // Stage A of ring phase km: acc[i] = Delta of this lane's C outputs
+    void emit_stage_a(std::ostringstream &o, int km, std::vector<int> *thetas) const {
+        std::vector<Read> reads;
+        std::vector<std::string> compute;
+        const int c = g_.c;
+        bool first = true;
+        int tcount = 0;
+        for (const Unit &u : g_.units) {
+            const char *sg = u.sign > 0 ? "+" : "-";
+            const int b_hi = u.b_lo + u.width - 1;
+            const int base_col = g_.hb - b_hi;  // element 0 of the unit for output 0 (lane part l*C is in the base)
+            const int first_read = static_cast<int>(reads.size());
+            const int n_el = c + u.width - 1;
+            for (int j = 0; j < n_el; ++j) {
+                reads.push_back(tap_address(km, u.a, base_col + j, thetas));
+                compute.push_back("");
+            }
+            auto e = [&](int j) { return "ea" + std::to_string(first_read + j); };
+            if (u.width == 1) {
+                for (int i = 0; i < c; ++i) {
+                    std::ostringstream s;
+                    if (first) s << "        acc" << i << " = " << (u.sign > 0 ? "" : "-") << e(i) << ";\n";
+                    else s << "        acc" << i << " " << sg << "= " << e(i) << ";\n";
+                    compute[first_read + i] = s.str();
+                }
+            } else {
+                // sliding sum: T_0 after element w-1, T_i after element i+w-1
+                const std::string t = "tw" + std::to_string(tcount++);
+                for (int i = 0; i < c; ++i) {
+                    std::ostringstream s;
+                    if (i == 0) {
+                        s << "        double " << t << " = " << e(0);
+                        for (int j = 1; j < u.width; ++j) s << " + " << e(j);
+                        s << ";\n";
+                    } else {
+                        s << "        " << t << " += " << e(i + u.width - 1) << " - " << e(i - 1) << ";\n";
+                    }
+                    if (first) s << "        acc" << i << " = " << (u.sign > 0 ? "" : "-") << t << ";\n";
+                    else s << "        acc" << i << " " << sg << "= " << t << ";\n";
+                    compute[first_read + i + u.width - 1] = s.str();
+                }
+            }
+            first = false;
+        }
+        emit_pipeline(o, "ea", reads, compute);
+    }
+
+    // Stage B of ring phase km, straight-line form (all NR rows interior): tid < Q
+    void emit_stage_b(std::ostringstream &o, int km) const {
+        std::vector<Read> reads;
+        std::vector<std::string> compute;
+        for (int r = 0; r < kNR; ++r) {
+            const int slot = (kNR * km + g_.a_hi + r) % g_.ms;
+            Read x;
+            if (slot < g_.hs) {
+                x.base = "xb0";
+                x.imm = slot * g_.pb;
+            } else {
+                x.base = "xb1";
+                x.imm = (slot - g_.hs) * g_.pb;
+            }
+            reads.push_back(x);
+            compute.push_back("");
+            Read d;
+            d.base = "db";
+            d.imm = r * g_.dpb;
+            reads.push_back(d);
+            std::ostringstream s;
+            const int ix = 2 * r, id = 2 * r + 1;
+            s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n"
+              << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8
+              << "u, 0);\n          S += eb" << id << "; }\n";
+            compute.push_back(s.str());
+        }
+        emit_pipeline(o, "eb", reads, compute);
+    }
+
+    std::string source() const {
+        std::ostringstream o;
+        const Geom &g = g_;
+        o << "// generated by parrm_filter_comb.hip -- q " << g.q << ", C " << g.c << ", " << g.units.size() << " delta units\n";
+        o << "typedef unsigned int u32;\ntypedef unsigned int u32x2 __attribute__((ext_vector_type(2)));\n";
+        o << "#define LDS_AS __attribute__((address_space(3)))\n";
+        o << "#define Q " << g.q << "\n#define CC " << g.c << "\n#define NR " << kNR << "\n#define MS " << g.ms << "\n#define HB " << g.hb
+          << "\n#define NCOL " << g.ncol << "\n#define PB " << g.pb << "\n#define DPB " << g.dpb << "\n#define AHI " << g.a_hi
+          << "\n#define ALO (" << g.a_lo << ")\n#define RING_BYTES " << g.ring_bytes << "\n#define LDS_TOTAL " << g.lds_total
+          << "\n#define HSTEP " << g.hs * g.pb << "\n#define NL2 " << (g.pb / 16 - 64) << "\n#define N_RUNS " << g.runs.size() << "\n";
+        o << "__device__ const int RUN_A[N_RUNS] = {";
+        for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].a;
+        o << "};\n__device__ const int RUN_BLO[N_RUNS] = {";
+        for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].b_lo;
+        o << "};\n__device__ const int RUN_BHI[N_RUNS] = {";
+        for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].b_hi;
+        o << "};\n";
+        o << R"SRC(
+struct CombArgs {
+    const double *x;
+    double *y;
+    long long n_chans, buf_first, buf_len, out_first, out_len, n_total, ldx, ldy;
+    const int *tapcum;
+    long long stretch_len, n_stretch;
+    double inv_taps;
+    int hw, pad;
+};
+
+__device__ __forceinline__ u32 lds_off(const void *p) { return (u32)(size_t)(const LDS_AS void *)p; }
+
+// one output of a row that touches an end of the recording (divisor = taps inside the recording, parrm.py:862-866)
+__device__ __noinline__ void emit_edge(double *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
+                                       long long n, double xc, double s) {
+    double y;
+    if (n >= hw && n + hw < n_total) {
+        y = __builtin_fma(-s, inv_taps, xc);
+    } else {
+        const long long w_hi = n < hw ? n : hw;
+        long long w_lo = n - n_total + 1;
+        if (w_lo < -hw) w_lo = -hw;
+        int v = 0;
+        if (w_hi >= w_lo) v = tapcum[w_hi + hw + 1] - tapcum[w_lo + hw];
+        y = v > 0 ? xc - s / (double)v : s * 0.0;  // no tap inside: 0, a poisoned sum stays visible for the repair pass
+    }
+    *yout = y;
+}
+
+extern "C" __global__ void __launch_bounds__(256) parrm_comb_kernel(CombArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
+    const u32 ring = lds_off(smem);
+    const u32 dbuf = ring + RING_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (explicitly wave-uniform: the buffer descriptors and row offsets below must live in scalar registers)
+    const u32 n_str = (u32)a.n_stretch;
+    const u32 ch32 = __builtin_amdgcn_readfirstlane(blockIdx.x / n_str);
+    const long long ch = ch32;
+    const long long st = blockIdx.x - ch32 * n_str;
+    const long long s0 = a.out_first + st * a.stretch_len;  // sample of (row 0, residue 0)
+    long long s_end = s0 + a.stretch_len;
+    if (s_end > a.out_first + a.out_len) s_end = a.out_first + a.out_len;
+    const int rows_total = (int)((s_end - s0 + Q - 1) / Q);
+    const int n_iter = (rows_total + NR - 1) / NR;
+    const double *xrow = a.x + ch * a.ldx;  // sample n at xrow[n - buf_first]
+    const long long lim_lo = a.buf_first > 0 ? a.buf_first : 0;
+    long long lim_hi = a.buf_first + a.buf_len;
+    if (lim_hi > a.n_total) lim_hi = a.n_total;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xrow), 0, (int)(a.buf_len * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y + ch * a.ldy, 0, (int)(a.out_len * 8), 0x00020000);
+    const double inv_taps = a.inv_taps;
+    int irregular = 0;  // > 0: a slow path ran lately, the counted vmcnt below does not hold -> drain
+
+    // ring row m (sample of column 0: s0 + m*Q - HB) into the slot at byte offset `sb`; wave-uniform arguments
+    auto load_row = [&](int m, u32 sb) {
+        const long long lo = s0 + (long long)m * Q - HB;
+        if (lo >= lim_lo && lo + NCOL <= lim_hi) {
+            const u32 soff = (u32)((lo - a.buf_first) * 8);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void *)(smem + sb), 16, lane * 16, soff, 0, 0);
+            if (lane < NL2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void *)(smem + sb + 1024), 16, lane * 16, soff + 1024, 0, 0);
+        } else {
+            irregular = 2;
+#pragma unroll 1
+            for (int col = lane; col < NCOL; col += 64) {
+                const long long n = lo + col;
+                const double v = (n >= lim_lo && n < lim_hi) ? xrow[n - a.buf_first] : 0.0;
+                *reinterpret_cast<double *>(smem + sb + col * 8) = v;
+            }
+        }
+    };
+
+    // prologue: rows [-AHI, -ALO + 2 NR) -> slots 0 ..
+    for (int j = wave; j < AHI - ALO + 2 * NR; j += 4) load_row(j - AHI, (u32)j * PB);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // running tap sum of row 0, evaluated tap by tap (thread = residue)
+    double S = 0.0;
+    if (tid < Q) {
+#pragma unroll 1
+        for (int rr = 0; rr < N_RUNS; ++rr) {
+            const double *rowp = reinterpret_cast<const double *>(smem + (AHI - RUN_A[rr]) * PB) + (HB + tid);
+            for (int b = RUN_BLO[rr]; b <= RUN_BHI[rr]; ++b) S += rowp[-b];
+        }
+    }
+    // stage-A lane: row r of the iteration, residues [l*CC, l*CC + CC)
+    const int gi = tid >> 4, l = tid & 15;
+    const int r = (gi >> 2) + 4 * (gi & 3);
+    const u32 B0 = ring + r * PB + l * (CC * 8);
+    const u32 B1 = B0 + HSTEP;
+)SRC";
+        // wrap bases are declared after the bodies are generated (we need to know which thresholds occur)
+        std::ostringstream bodies;
+        std::vector<int> thetas;
+        for (int km = 0; km < g.period; ++km) {
+            bodies << "        // ------------------------------------------------------------ ring phase " << km << "\n        {\n";
+            // 1. request the rows of iteration k + 2
+            const int sb = (kNR * (km + 2) + g.a_hi - g.a_lo) % g.ms;
+            bodies << "#pragma unroll 1\n        for (int jj = 0; jj < 4; ++jj) {\n            int sl = " << sb
+                   << " + wave + 4 * jj;\n            if (sl >= MS) sl -= MS;\n            load_row((k + 2) * NR - ALO + wave + 4 * jj, (u32)sl * PB);\n        }\n";
+            // 2. stage A
+            bodies << "        double";
+            for (int i = 0; i < g.c; ++i) bodies << (i ? ", " : " ") << "acc" << i;
+            bodies << ";\n";
+            emit_stage_a(bodies, km, &thetas);
+            // 3. everyone is done reading the Delta buffer of the previous iteration
+            bodies << "        asm volatile(\"s_barrier\" ::: \"memory\");\n";
+            for (int i = 0; i < g.c; ++i)
+                bodies << "        *reinterpret_cast<LDS_AS double *>(dwr + " << 8 * i << ") = acc" << i << ";\n";
+            // 4. rows of iteration k + 1 landed (requested one iteration ago), Delta values written
+            bodies << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
+                   << "        else if (wave_has_b) asm volatile(\"s_waitcnt vmcnt(" << (kNR + 8) << ")\" ::: \"memory\");\n"
+                   << "        else asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");\n"
+                   << "        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n";
+            // 5. stage B
+            const int slot_b = (kNR * km + g.a_hi) % g.ms;
+            bodies << "        {\n        const long long nrow = s0 + (long long)k * (NR * Q);\n"
+                   << "        const bool fast = (k + 1) * NR * (long long)Q + s0 <= s_end && nrow >= a.hw && nrow + NR * Q - 1 + a.hw < a.n_total;\n"
+                   << "        if (fast) {\n          if (tid < Q) {\n          const u32 yoff = ystart + (u32)k * (u32)(NR * Q * 8);\n";
+            emit_stage_b(bodies, km);
+            bodies << "          }\n        } else {\n          irregular = 2;\n          asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+                   << "          if (tid < Q) {\n#pragma unroll 1\n            for (int rr = 0; rr < NR; ++rr) {\n              int sl = " << slot_b
+                   << " + rr;\n              if (sl >= MS) sl -= MS;\n"
+                   << "              const double xr = *reinterpret_cast<const double *>(smem + sl * PB + (HB + tid) * 8);\n"
+                   << "              const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + rr * DPB + tid * 8);\n"
+                   << "              const int m = k * NR + rr;\n              const long long n = s0 + (long long)m * Q + tid;\n"
+                   << "              if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);\n              S += dr;\n            }\n          }\n        }\n        }\n";
+            bodies << "        }\n";
+            bodies << "        if (++k >= n_iter) break;\n";
+        }
+        std::sort(thetas.begin(), thetas.end());
+        for (int th : thetas) o << "    const u32 B1w" << th << " = B1 - (r >= " << th << " ? (u32)RING_BYTES : 0u);\n";
+        o << R"SRC(    const u32 dwr = dbuf + r * DPB + l * (CC * 8);
+    // stage-B lane: residue tid
+    const u32 xb0 = ring + (HB + tid) * 8, xb1 = xb0 + HSTEP;
+    const u32 db = dbuf + tid * 8;
+    const u32 ystart = (u32)((s0 - a.out_first) * 8) + (u32)tid * 8u;
+    const bool wave_has_b = wave * 64 < Q;
+    int k = 0;
+    if (n_iter > 0) {
+    while (true) {
+)SRC";
+        o << bodies.str();
+        o << R"SRC(    }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+)SRC";
+        return o.str();
+    }
+
+   private:
+    const Geom &g_;
+    int batch_;
+};
+
+// ---------------------------------------------------------------------------------------------- code objects
+uint64_t fnv1a(const std::string &s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char ch : s) {
+        h ^= ch;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+std::string library_dir() {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void *>(&fnv1a), &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t k = p.rfind('/');
+        if (k != std::string::npos) return p.substr(0, k);
+    }
+    return ".";
+}
+
+std::string user_cache_dir() {
+    if (const char *e = getenv("PARRM_KERNEL_CACHE")) return e;
+    if (const char *h = getenv("HOME")) return std::string(h) + "/.cache/pyparrm_amd";
+    return "/tmp/pyparrm_amd_cache";
+}
+
+bool read_file(const std::string &path, std::vector<char> *out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return !out->empty();
+}
+
+bool write_file_atomic(const std::string &path, const std::vector<char> &data) {
+    const std::string tmp = path + ".tmp" + std::to_string(static_cast<long long>(getpid()));
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) return false;
+        f.write(data.data(), static_cast<std::streamsize>(data.size()));
+        if (!f) return false;
+    }
+    return rename(tmp.c_str(), path.c_str()) == 0;
+}
+
+void make_dirs(const std::string &dir) {
+    std::string acc;
+    for (size_t i = 0; i <= dir.size(); ++i) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!acc.empty()) (void)mkdir(acc.c_str(), 0755);
+        }
+        if (i < dir.size()) acc.push_back(dir[i]);
+    }
+}
+
+bool compile_source(const std::string &src, std::vector<char> *code, std::string *log) {
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "parrm_comb.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        *log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    size_t ls = 0;
+    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        log->resize(ls);
+        (void)hiprtcGetProgramLog(prog, &(*log)[0]);
+    }
+    bool ok = rc == HIPRTC_SUCCESS;
+    if (ok) {
+        size_t cs = 0;
+        ok = hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
+        if (ok) {
+            code->resize(cs);
+            ok = hiprtcGetCode(prog, code->data()) == HIPRTC_SUCCESS;
+        }
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    return ok;
+}
+
+std::string code_name(const std::string &src) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "comb_%016llx.hsaco", static_cast<unsigned long long>(fnv1a(src)));
+    return buf;
+}
+
+// code object for a source text: in-tree directory, user cache, else hipRTC (result stored in the user cache)
+bool code_for_source(const std::string &src, std::vector<char> *code, std::string *why) {
+    const std::string name = code_name(src);
+    if (!getenv("PARRM_COMB_NO_CACHE")) {
+        if (read_file(library_dir() + "/kernels/" + name, code)) return true;
+        if (read_file(user_cache_dir() + "/" + name, code)) return true;
+    }
+    std::string log;
+    if (!compile_source(src, code, &log)) {
+        *why = "hipRTC: " + log;
+        return false;
+    }
+    make_dirs(user_cache_dir());
+    (void)write_file_atomic(user_cache_dir() + "/" + name, *code);
+    return true;
+}
+
+int pick_batch() {
+    int b = 7;
+    if (const char *e = getenv("PARRM_COMB_BATCH")) b = atoi(e);
+    return std::min(7, std::max(2, b));
+}
+
+// device struct of the generated source
+struct CombArgs {
+    const double *x;
+    double *y;
+    long long n_chans, buf_first, buf_len, out_first, out_len, n_total, ldx, ldy;
+    const int *tapcum;
+    long long stretch_len, n_stretch;
+    double inv_taps;
+    int hw, pad;
+};
+
+}  // namespace
+
+struct CombKernel {
+    Geom geom;
+    std::string source;
+    hipModule_t module = nullptr;
+    hipFunction_t func = nullptr;
+    std::string error;
+};
+
+// Geometry + source for a tap mask (no device needed); nullptr when this kernel cannot take the filter.
+CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q) {
+    Geom g;
+    if (!make_geom(tap, hw, q, &g)) return nullptr;
+    auto *k = new CombKernel();
+    k->geom = g;
+    k->source = Emitter(k->geom, pick_batch()).source();
+    return k;
+}
+
+void comb_destroy(CombKernel *k) {
+    if (!k) return;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+}
+
+// Loads (compiling if no cached code object exists) the kernel on the current device.
+bool comb_load(CombKernel *k) {
+    if (k->func) return true;
+    std::vector<char> code;
+    if (!code_for_source(k->source, &code, &k->error)) return false;
+    hipError_t e = hipModuleLoadData(&k->module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&k->func, k->module, "parrm_comb_kernel");
+    if (e != hipSuccess) {
+        k->error = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+        if (k->module) (void)hipModuleUnload(k->module);
+        k->module = nullptr;
+        k->func = nullptr;
+        return false;
+    }
+    return true;
+}
+
+const char *comb_error(const CombKernel *k) { return k->error.c_str(); }
+int comb_stride(const CombKernel *k) { return k->geom.q; }
+
+// The stride the plan's guarded phase search picks for this filter (0: none, or only the wrap form).
+int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw) {
+    parrm_filter_plan tmp;
+    std::vector<int32_t> table;
+    plan_phase(tap, hw, &tmp, &table);
+    return (tmp.phase.n_groups > 0 && !tmp.phase.wrap) ? tmp.phase.q : 0;
+}
+
+// Launch for float64 in / float64 out, mode 0.  Fills a->stretch_len / a->n_stretch (the repair pass needs them).
+int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
+    FilterArgs &a = *args;
+    const Geom &g = k->geom;
+    // Stretch length: one workgroup per CU (256 resident); a stretch costs its rows plus a prologue of
+    // a_hi - a_lo + 2 NR rows and one tap-by-tap evaluation (~ 5 rows' worth).  Long recordings: ~1 M samples.
+    const int64_t q = g.q;
+    const int64_t prologue_rows = g.a_hi - g.a_lo + 2 * kNR + 8;
+    int64_t target = int64_t{1} << 20;
+    if (const char *env = getenv("PARRM_COMB_STRETCH")) target = std::max<int64_t>(atoll(env), q * kNR);
+    int64_t rows = std::max<int64_t>(kNR, (target / q) / kNR * kNR);
+    auto blocks_for = [&](int64_t r) { return a.plan_chans * ((a.out_len + r * q - 1) / (r * q)); };
+    if (blocks_for(rows) < 2048 && !getenv("PARRM_COMB_STRETCH")) {
+        const int64_t resident = 256;
+        double best = 1e300;
+        int64_t best_rows = rows;
+        const int64_t max_stretches = std::max<int64_t>(1, a.out_len / (static_cast<int64_t>(4) * kNR * q));
+        for (int64_t per_chan = 1; per_chan <= std::min<int64_t>(max_stretches, 4096); ++per_chan) {
+            const int64_t r = ((a.out_len + per_chan - 1) / per_chan + q - 1) / q;
+            const int64_t rr = (r + kNR - 1) / kNR * kNR;
+            const int64_t blocks = blocks_for(rr);
+            const int64_t rounds = (blocks + resident - 1) / resident;
+            const double cost = static_cast<double>(rounds) * static_cast<double>(rr + prologue_rows);
+            if (cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                best_rows = rr;
+            }
+            if (blocks > 4096) break;
+        }
+        rows = best_rows;
+    }
+    a.stretch_len = rows * q;
+    a.n_stretch = (a.out_len + a.stretch_len - 1) / a.stretch_len;
+    const int64_t blocks = a.n_chans * a.n_stretch;
+    PARRM_REQUIRE(blocks <= 0x7fffffffLL, "filter: too many workgroups for one launch");
+    CombArgs ca{};
+    ca.x = static_cast<const double *>(a.x);
+    ca.y = static_cast<double *>(a.y);
+    ca.n_chans = a.n_chans;
+    ca.buf_first = a.buf_first;
+    ca.buf_len = a.buf_len;
+    ca.out_first = a.out_first;
+    ca.out_len = a.out_len;
+    ca.n_total = a.n_total;
+    ca.ldx = a.ldx;
+    ca.ldy = a.ldy;
+    ca.tapcum = a.tapcum;
+    ca.stretch_len = a.stretch_len;
+    ca.n_stretch = a.n_stretch;
+    ca.inv_taps = a.inv_taps;
+    ca.hw = a.hw;
+    size_t sz = sizeof(ca);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ca, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    PARRM_HIP_CHECK(hipModuleLaunchKernel(k->func, static_cast<unsigned>(blocks), 1, 1, kThreads, 1, 1, 0, stream, nullptr, config));
+    return PARRM_OK;
+}
+
+// Can this launch take the comb kernel?  (float64 both sides is the caller's test.)
+bool comb_accepts(const CombKernel *k, const FilterArgs &a) {
+    (void)k;
+    return a.buf_len * 8 < 0x7ffff000LL && a.out_len * 8 < 0x7ffff000LL;
+}
+
+}  // namespace parrm_filter
+
+extern "C" {
+
+// Build-time helper (no GPU needed): generate the comb kernel for a filter array (parrm.py:803-833 layout) and
+// store its code object as <out_dir>/comb_<hash>.hsaco -- __graft_entry__.build() ships the BASELINE geometry
+// that way, so a fresh box does not compile at first use.  `stride` 0: the stride the plan would choose is not
+// known without a plan -- pass the phase stride (parrm_filter_plan_info.phase_stride) or let it be searched.
+int parrm_filter_comb_precompile(const double *h_filter, int64_t filter_len, int64_t stride, const char *out_dir,
+                                 char *source_path, size_t source_path_len) {
+    PARRM_REQUIRE(h_filter && out_dir, "comb_precompile: NULL argument");
+    PARRM_REQUIRE(filter_len >= 3 && (filter_len & 1), "comb_precompile: filter length must be odd and >= 3");
+    const int64_t hw = (filter_len - 1) / 2;
+    std::vector<int8_t> tap(filter_len, 0);
+    for (int64_t i = 0; i < filter_len; ++i)
+        if (i != hw && h_filter[i] != 0.0) tap[i] = 1;
+    if (stride == 0) stride = parrm_filter::comb_search_stride(tap, hw);
+    parrm_filter::CombKernel *k = stride ? parrm_filter::comb_generate(tap, hw, stride) : nullptr;
+    if (!k) {
+        parrm::set_error("comb_precompile: the generated kernel does not take this filter");
+        return PARRM_ERR_INVALID;
+    }
+    std::vector<char> code;
+    std::string log;
+    const bool ok = parrm_filter::compile_source(k->source, &code, &log);
+    const std::string name = parrm_filter::code_name(k->source);
+    int rc = PARRM_OK;
+    if (!ok) {
+        parrm::set_error("comb_precompile: %s", log.c_str());
+        rc = PARRM_ERR_HIP;
+    } else {
+        parrm_filter::make_dirs(out_dir);
+        if (!parrm_filter::write_file_atomic(std::string(out_dir) + "/" + name, code)) {
+            parrm::set_error("comb_precompile: cannot write %s/%s", out_dir, name.c_str());
+            rc = PARRM_ERR_INVALID;
+        }
+        if (source_path && source_path_len) {
+            const std::string sp = std::string(out_dir) + "/" + name.substr(0, name.size() - 6) + ".hip";
+            std::ofstream f(sp);
+            f << k->source;
+            snprintf(source_path, source_path_len, "%s", sp.c_str());
+        }
+    }
+    parrm_filter::comb_destroy(k);
+    return rc;
+}
+
+}  // extern "C"

@@ -180,6 +180,18 @@ template <typename TI, typename TO>
 int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, hipStream_t stream);
 }  // namespace parrm_filter
 
+namespace parrm_filter {
+// parrm_filter_comb.hip: the per-filter generated kernel (float64 recordings, comb filters with q in [96, 256])
+struct CombKernel;
+CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q);
+void comb_destroy(CombKernel *k);
+bool comb_load(CombKernel *k);  // code object from the caches or hipRTC, loaded on the current device
+const char *comb_error(const CombKernel *k);
+bool comb_accepts(const CombKernel *k, const FilterArgs &a);
+int launch_comb(const CombKernel *k, FilterArgs *a, hipStream_t stream);
+int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw);
+}  // namespace parrm_filter
+
 struct parrm_filter_plan {
     int device = 0;
     int64_t hw = 0, n_taps = 0, n_runs = 0;
@@ -204,6 +216,11 @@ struct parrm_filter_plan {
     // seg_centre[k] is the offset w the k-th sub-plan's centre stands for.  Empty: not segmented.
     std::vector<parrm_filter_plan *> segments;
     std::vector<int64_t> seg_centre;
+    // Generated kernel (parrm_filter_comb.hip).  The tap mask is kept so that the kernel can be generated at the
+    // first launch large enough to pay for a compile; comb_state: 0 not tried, 1 loaded, -1 unavailable.
+    std::vector<int8_t> tap_mask;
+    mutable parrm_filter::CombKernel *comb = nullptr;
+    mutable int comb_state = 0;
 };
 
 
