@@ -18,10 +18,15 @@
 //   * Stage B (outputs).  Thread = residue (coalesced 8-byte stores as before) walks the NR rows of the
 //     iteration: y = x - S / n_taps, S += Delta.  The Delta values change hands through an LDS buffer; S stays
 //     in a register for the whole stretch, so there is no chain between row groups at all.
-//   * Rows land in the LDS ring by LDS-DMA (buffer_load_dwordx4 ... lds), two iterations ahead: no staging
-//     registers, no ds_write traffic, 16-byte coalesced requests.  Ring layout: row-major [slot][PITCH] with HB
-//     halo columns each side (loaded, not mirrored); PITCH = 4 mod 8 and the two rows of a half-wave four
-//     slots apart make every ds_read_b64 conflict-free.
+//   * The delta units are split between two wave sets (8 waves per workgroup, one workgroup per CU): both sets
+//     work on the same NR rows, each on half of the taps, and stage B adds the two partial Deltas.  Two waves
+//     per SIMD let one wave's LDS issue overlap the other's float64 adds (first version, one set of four waves:
+//     5.6 ms of pure issue time for 256 ch x 10 M; the ring of a second workgroup does not fit the LDS).
+//   * Rows are requested P = 4 iterations ahead into registers (16-byte coalesced buffer loads, ~90 KB in
+//     flight per CU: the first version staged rows by LDS-DMA two iterations ahead, 48 KB in flight, and its
+//     read stream alone ran at 4.1 TB/s) and copied into the ring one iteration ahead (ds_write_b128).  Ring
+//     layout: row-major [slot][PITCH] with HB halo columns each side (loaded, not mirrored); PITCH = 4 mod 8 and
+//     the two rows of a half-wave four slots apart make every ds_read_b64 conflict-free.
 //   * Rows that touch the ends of the recording / of the addressable window are filled and emitted by a
 //     generic slow path (zero padding, divisor from the cumulative tap counts), everything else is
 //     straight-line code.
@@ -51,7 +56,7 @@ namespace parrm_filter {
 namespace {
 
 constexpr int kNR = 16;       // rows per iteration (4 waves x 4 rows)
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;  // two wave sets of four waves
 constexpr int kLdsLimit = 160 * 1024;
 
 struct Unit {  // one delta element: `width` adjacent taps of one sign in row m - a, offsets b_lo .. b_lo + width - 1
@@ -64,6 +69,7 @@ struct Run {   // full-tap run for the per-stretch initialisation
 struct Geom {
     int q = 0, c = 0, hb = 0, ncol = 0, pitch = 0, ms = 0, a_lo = 0, a_hi = 0;
     int pb = 0, dpb = 0, ring_bytes = 0, lds_total = 0, hs = 0, period = 0;
+    int ofs = 0, ch16 = 0, d_bytes = 0, nld = 0;  // slot of row m: (m + ofs) mod ms; 16-byte chunks per row; one Delta buffer; loads per lane
     int n_taps = 0;
     std::vector<Unit> units;
     std::vector<Run> runs;
@@ -142,17 +148,25 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     g->pitch = pitch;
     g->pb = pitch * 8;
     g->dpb = 16 * c * 8;
-    // live rows when the rows of iteration k+2 are requested: [16k - max(16, a_hi), 16k + 48 - a_lo)
-    const int live = std::max(kNR, g->a_hi) + 3 * kNR - g->a_lo;
+    // Rows of iteration k+1 are copied into the ring during iteration k: live rows then are
+    // [16k - max(a_hi, 16), 16(k+1) - a_lo + 16)  (stage B of iteration k-1 may still read its own rows).
+    const int live = std::max(kNR, g->a_hi) + 2 * kNR - g->a_lo;
     g->ms = (live + kNR - 1) / kNR * kNR;
     g->period = g->ms / kNR;
+    // slot of row m = (m + ofs) mod ms with ofs = a_lo (mod 16), so that the 16 rows loaded for one iteration
+    // ([16k - a_lo, 16k - a_lo + 16)) never straddle the ring's end
+    g->ofs = g->a_lo;
+    while (g->ofs < g->a_hi) g->ofs += kNR;
     g->hs = g->ms / 2;
     g->ring_bytes = g->ms * g->pb;
-    g->lds_total = g->ring_bytes + kNR * g->dpb;
+    g->d_bytes = kNR * g->dpb;
+    g->lds_total = g->ring_bytes + 2 * g->d_bytes;
+    g->ch16 = g->pb / 16;
+    g->nld = (kNR * g->ch16 + kThreads - 1) / kThreads;
     if (g->lds_total > kLdsLimit) return false;
-    if (g->hs * g->pb + g->pb > 65000) return false;     // immediates of ds_read are 16 bits
-    if (g->a_hi - g->a_lo + 2 * kNR > g->ms) return false;  // prologue fill must not wrap
-    if (g->pb / 16 > 128 || g->pb / 16 <= 64) return false;  // two DMA instructions per row
+    if (g->hs * g->pb + g->pb > 65000) return false;         // immediates of ds_read are 16 bits
+    if (g->ofs - g->a_lo + kNR > g->ms) return false;         // prologue fill must not wrap
+    if (g->period < 2 || g->period > 6) return false;
     return true;
 }
 
@@ -164,11 +178,15 @@ struct Read {
 
 class Emitter {
    public:
-    explicit Emitter(const Geom &g, int batch) : g_(g), batch_(batch) {}
+    explicit Emitter(const Geom &g, int batch) : g_(g), batch_(batch) {
+        // profiling ablations (results wrong by construction): 1 no tap reads, 2 no output stores, 4 no row requests,
+        // 8 no second barrier, 16 no stage B at all.  Part of the source text, so each has its own code object.
+        if (const char *e = getenv("PARRM_COMB_DEBUG")) debug_ = atoi(e);
+    }
 
     // (base register, immediate) of element `col` of ring row m - a for lane row r, at ring phase km
     Read tap_address(int km, int a, int col, std::vector<int> *thetas) const {
-        int slot0 = (kNR * km + g_.a_hi - a) % g_.ms;
+        int slot0 = (kNR * km + g_.ofs - a) % g_.ms;
         if (slot0 < 0) slot0 += g_.ms;
         Read r;
         if (slot0 + kNR - 1 < g_.ms) {
@@ -194,7 +212,8 @@ class Emitter {
     //   reads[i]        : where value e<prefix><i> comes from
     //   compute[i]      : statements that may run once read i (and every earlier one) is back
     void emit_pipeline(std::ostringstream &o, const std::string &prefix, const std::vector<Read> &reads,
-                       const std::vector<std::string> &compute) const {
+                       const std::vector<std::string> &compute, int batch = 0) const {
+        const int batch_ = batch ? batch : this->batch_;
         const int n = static_cast<int>(reads.size());
         o << "        double";
         for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << prefix << i;
@@ -232,13 +251,13 @@ class Emitter {
     }
 
     // Stage A of ring phase km: acc[i] = Delta of this lane's C outputs
-    void emit_stage_a(std::ostringstream &o, int km, std::vector<int> *thetas) const {
+    void emit_stage_a(std::ostringstream &o, int km, const std::vector<Unit> &units, std::vector<int> *thetas) const {
         std::vector<Read> reads;
         std::vector<std::string> compute;
         const int c = g_.c;
         bool first = true;
         int tcount = 0;
-        for (const Unit &u : g_.units) {
+        for (const Unit &u : units) {
             const char *sg = u.sign > 0 ? "+" : "-";
             const int b_hi = u.b_lo + u.width - 1;
             const int base_col = g_.hb - b_hi;  // element 0 of the unit for output 0 (lane part l*C is in the base)
@@ -275,6 +294,10 @@ class Emitter {
             }
             first = false;
         }
+        if ((debug_ & 1) || units.empty()) {
+            for (int i = 0; i < c; ++i) o << "        acc" << i << " = 0.0;\n";
+            return;
+        }
         emit_pipeline(o, "ea", reads, compute);
     }
 
@@ -283,7 +306,7 @@ class Emitter {
         std::vector<Read> reads;
         std::vector<std::string> compute;
         for (int r = 0; r < kNR; ++r) {
-            const int slot = (kNR * km + g_.a_hi + r) % g_.ms;
+            const int slot = (kNR * km + g_.ofs + r) % g_.ms;
             Read x;
             if (slot < g_.hs) {
                 x.base = "xb0";
@@ -294,30 +317,92 @@ class Emitter {
             }
             reads.push_back(x);
             compute.push_back("");
-            Read d;
-            d.base = "db";
-            d.imm = r * g_.dpb;
-            reads.push_back(d);
+            reads.push_back({"db", r * g_.dpb});
+            compute.push_back("");
+            reads.push_back({"db", r * g_.dpb + g_.d_bytes});
             std::ostringstream s;
-            const int ix = 2 * r, id = 2 * r + 1;
-            s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n"
-              << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8
-              << "u, 0);\n          S += eb" << id << "; }\n";
+            const int ix = 3 * r;
+            s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n";
+            if (debug_ & 2) s << "          asm volatile(\"\" :: \"v\"(yv));\n";
+            else s << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n";
+            s << "          S += eb" << ix + 1 << " + eb" << ix + 2 << "; }\n";
             compute.push_back(s.str());
         }
-        emit_pipeline(o, "eb", reads, compute);
+        emit_pipeline(o, "eb", reads, compute, 6);
+    }
+
+    // the units dealt over the two wave sets, balanced by LDS reads
+    void split_units(std::vector<Unit> (&half)[2]) const {
+        std::vector<Unit> sorted = g_.units;
+        std::stable_sort(sorted.begin(), sorted.end(), [](const Unit &x, const Unit &y) { return x.width > y.width; });
+        int load[2] = {0, 0};
+        for (const Unit &u : sorted) {
+            const int h = load[1] < load[0] ? 1 : 0;
+            half[h].push_back(u);
+            load[h] += g_.c + u.width - 1;
+        }
+    }
+
+    // Request the NR rows of iteration `kk` (an expression) into register set `set`.  The loads are inline asm and
+    // the wait before the set is copied into the ring is a COUNTED vmcnt written by hand (emit_write_iter): with
+    // compiler-visible loads hipcc drained the queue (vmcnt(0)) once per ring period, i.e. gave up the whole
+    // prefetch depth every P iterations.  Vector memory operations retire in issue order, so "at most N
+    // outstanding" with N = everything issued after the set's loads on the regular path (the loads and output
+    // stores of the P-1 iterations since) means the set has landed; any path that issues a different number of
+    // operations (rows at the ends of the window, edge outputs) raises `irregular` and the next P waits drain.
+    void emit_load_iter(std::ostringstream &o, int set, const std::string &kk) const {
+        if (debug_ & 4) {
+            for (int i = 0; i < g_.nld; ++i) o << "        pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
+            return;
+        }
+        o << "        {\n        const long long lo = s0 + (long long)(NR * (" << kk << ") - ALO) * Q - HB;\n"
+          << "        if (lo >= lim_lo && lo + (NR - 1) * Q + NCOL <= lim_hi) {\n"
+          << "            const u32 soff = (u32)((lo - a.buf_first) * 8);\n            asm volatile(";
+        const int n = g_.nld;
+        for (int i = 0; i < n; ++i)
+            o << "\"buffer_load_dwordx4 %" << i << ", %" << n + i << ", %" << 2 * n << ", %" << 2 * n + 1 << " offen\\n\\t\"\n                         ";
+        o << "\"\"\n                         :";
+        for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << "\"=&v\"(pf" << set << "_" << i << ")";
+        o << "\n                         :";
+        for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << "\"v\"(goff" << i << ")";
+        o << ", \"s\"(xdesc), \"s\"(soff) : \"memory\");\n";
+        o << "        } else {\n            irregular = " << g_.period << ";\n";
+        for (int i = 0; i < g_.nld; ++i)
+            o << "            pf" << set << "_" << i << " = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, lo + nrel" << i << ");\n";
+        // (the empty asm makes the compiler wait for these loads HERE: left pending they would put its own
+        // vmcnt(0) in front of the ring copy of every iteration that merges with this path)
+        for (int i = 0; i < g_.nld; ++i) o << "            asm volatile(\"\" : \"+v\"(pf" << set << "_" << i << "));\n";
+        o << "        }\n        }\n";
+    }
+
+    // copy register set `set` into the ring slots that start at byte offset `sb`
+    void emit_write_iter(std::ostringstream &o, int set, int sb) const {
+        const bool partial = kNR * g_.ch16 % kThreads != 0;
+        const int younger_loads = (g_.period - 1) * g_.nld;
+        const int younger_all = std::min(63, (g_.period - 1) * (g_.nld + kNR));
+        o << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
+          << "        else if (wave_has_b) asm volatile(\"s_waitcnt vmcnt(" << younger_all << ")\" ::: \"memory\");\n"
+          << "        else asm volatile(\"s_waitcnt vmcnt(" << std::min(63, younger_loads) << ")\" ::: \"memory\");\n";
+        for (int i = 0; i < g_.nld; ++i) {
+            o << "        ";
+            if (partial && i == g_.nld - 1) o << "if (lvalid) ";
+            o << "*(LDS_AS u32x4 *)(loff" << i << " + " << sb << "u) = pf" << set << "_" << i << ";\n";
+        }
     }
 
     std::string source() const {
         std::ostringstream o;
         const Geom &g = g_;
+        const int P = g.period;
         o << "// generated by parrm_filter_comb.hip -- q " << g.q << ", C " << g.c << ", " << g.units.size() << " delta units\n";
-        o << "typedef unsigned int u32;\ntypedef unsigned int u32x2 __attribute__((ext_vector_type(2)));\n";
+        o << "typedef unsigned int u32;\ntypedef unsigned int u32x2 __attribute__((ext_vector_type(2)));\n"
+          << "typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));\n";
         o << "#define LDS_AS __attribute__((address_space(3)))\n";
         o << "#define Q " << g.q << "\n#define CC " << g.c << "\n#define NR " << kNR << "\n#define MS " << g.ms << "\n#define HB " << g.hb
           << "\n#define NCOL " << g.ncol << "\n#define PB " << g.pb << "\n#define DPB " << g.dpb << "\n#define AHI " << g.a_hi
-          << "\n#define ALO (" << g.a_lo << ")\n#define RING_BYTES " << g.ring_bytes << "\n#define LDS_TOTAL " << g.lds_total
-          << "\n#define HSTEP " << g.hs * g.pb << "\n#define NL2 " << (g.pb / 16 - 64) << "\n#define N_RUNS " << g.runs.size() << "\n";
+          << "\n#define ALO (" << g.a_lo << ")\n#define OFS " << g.ofs << "\n#define RING_BYTES " << g.ring_bytes << "\n#define DBYTES " << g.d_bytes
+          << "\n#define LDS_TOTAL " << g.lds_total << "\n#define HSTEP " << g.hs * g.pb << "\n#define CH16 " << g.ch16
+          << "\n#define PERIOD " << g.period << "\n#define NTHREADS " << kThreads << "\n#define N_RUNS " << g.runs.size() << "\n";
         o << "__device__ const int RUN_A[N_RUNS] = {";
         for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].a;
         o << "};\n__device__ const int RUN_BLO[N_RUNS] = {";
@@ -339,7 +424,7 @@ struct CombArgs {
 __device__ __forceinline__ u32 lds_off(const void *p) { return (u32)(size_t)(const LDS_AS void *)p; }
 
 // one output of a row that touches an end of the recording (divisor = taps inside the recording, parrm.py:862-866)
-__device__ __noinline__ void emit_edge(double *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
+__device__ __forceinline__ void emit_edge(double *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
                                        long long n, double xc, double s) {
     double y;
     if (n >= hw && n + hw < n_total) {
@@ -355,13 +440,19 @@ __device__ __noinline__ void emit_edge(double *yout, const int *tapcum, long lon
     *yout = y;
 }
 
-extern "C" __global__ void __launch_bounds__(256) parrm_comb_kernel(CombArgs a) {
+// samples n, n + 1 of a row, zero outside [lim_lo, lim_hi) (the ends of the recording / of the addressable window)
+__device__ __forceinline__ u32x4 load_pair_padded(const double *xrow, long long buf_first, long long lim_lo, long long lim_hi, long long n) {
+    const double v0 = (n >= lim_lo && n < lim_hi) ? xrow[n - buf_first] : 0.0;
+    const double v1 = (n + 1 >= lim_lo && n + 1 < lim_hi) ? xrow[n + 1 - buf_first] : 0.0;
+    const u32x2 w0 = __builtin_bit_cast(u32x2, v0), w1 = __builtin_bit_cast(u32x2, v1);
+    return u32x4{w0.x, w0.y, w1.x, w1.y};
+}
+
+extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
     const u32 ring = lds_off(smem);
     const u32 dbuf = ring + RING_BYTES;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (explicitly wave-uniform: the buffer descriptors and row offsets below must live in scalar registers)
     const u32 n_str = (u32)a.n_stretch;
     const u32 ch32 = __builtin_amdgcn_readfirstlane(blockIdx.x / n_str);
@@ -379,109 +470,125 @@ extern "C" __global__ void __launch_bounds__(256) parrm_comb_kernel(CombArgs a) 
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xrow), 0, (int)(a.buf_len * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y + ch * a.ldy, 0, (int)(a.out_len * 8), 0x00020000);
     const double inv_taps = a.inv_taps;
-    int irregular = 0;  // > 0: a slow path ran lately, the counted vmcnt below does not hold -> drain
+    // the same descriptor as four scalars, for the inline-asm row loads
+    u32x4 xdesc;
+    {
+        const unsigned long long xp = (unsigned long long)xrow;
+        xdesc.x = __builtin_amdgcn_readfirstlane((u32)xp);
+        xdesc.y = __builtin_amdgcn_readfirstlane((u32)(xp >> 32) & 0xffffu);
+        xdesc.z = __builtin_amdgcn_readfirstlane((u32)(a.buf_len * 8));
+        xdesc.w = 0x00020000u;
+    }
+    // > 0: the counted vmcnt of the ring copy does not hold (fewer operations were issued lately than the regular
+    // path issues: the first P-1 iterations of a stretch have no output stores behind them yet, rows at the ends
+    // of the window are fetched differently, edge outputs are stored differently) -> that wait drains the queue
+    int irregular = PERIOD - 1;
+    const bool wave_has_b = __builtin_amdgcn_readfirstlane(tid & ~63) < Q;
 
-    // ring row m (sample of column 0: s0 + m*Q - HB) into the slot at byte offset `sb`; wave-uniform arguments
-    auto load_row = [&](int m, u32 sb) {
-        const long long lo = s0 + (long long)m * Q - HB;
-        if (lo >= lim_lo && lo + NCOL <= lim_hi) {
-            const u32 soff = (u32)((lo - a.buf_first) * 8);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void *)(smem + sb), 16, lane * 16, soff, 0, 0);
-            if (lane < NL2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void *)(smem + sb + 1024), 16, lane * 16, soff + 1024, 0, 0);
-        } else {
-            irregular = 2;
+    // prologue: rows [-AHI, -ALO + NR) -> slots OFS - AHI .. (everything iteration 0 reads), 16-byte chunks
 #pragma unroll 1
-            for (int col = lane; col < NCOL; col += 64) {
-                const long long n = lo + col;
-                const double v = (n >= lim_lo && n < lim_hi) ? xrow[n - a.buf_first] : 0.0;
-                *reinterpret_cast<double *>(smem + sb + col * 8) = v;
-            }
-        }
-    };
-
-    // prologue: rows [-AHI, -ALO + 2 NR) -> slots 0 ..
-    for (int j = wave; j < AHI - ALO + 2 * NR; j += 4) load_row(j - AHI, (u32)j * PB);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = tid; t < (AHI - ALO + NR) * CH16; t += NTHREADS) {
+        const int row = t / CH16, c16 = t - row * CH16;
+        const long long n = s0 + (long long)(row - AHI) * Q - HB + 2 * c16;
+        *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, n);
+    }
     __syncthreads();
     // running tap sum of row 0, evaluated tap by tap (thread = residue)
     double S = 0.0;
     if (tid < Q) {
 #pragma unroll 1
         for (int rr = 0; rr < N_RUNS; ++rr) {
-            const double *rowp = reinterpret_cast<const double *>(smem + (AHI - RUN_A[rr]) * PB) + (HB + tid);
+            const double *rowp = reinterpret_cast<const double *>(smem + (OFS - RUN_A[rr]) * PB) + (HB + tid);
             for (int b = RUN_BLO[rr]; b <= RUN_BHI[rr]; ++b) S += rowp[-b];
         }
     }
-    // stage-A lane: row r of the iteration, residues [l*CC, l*CC + CC)
-    const int gi = tid >> 4, l = tid & 15;
+    // stage-A lane: wave set hs takes its half of the delta units for row r of the iteration, residues [l*CC, l*CC + CC)
+    const int hs = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int gi = (tid & 255) >> 4, l = tid & 15;
     const int r = (gi >> 2) + 4 * (gi & 3);
     const u32 B0 = ring + r * PB + l * (CC * 8);
     const u32 B1 = B0 + HSTEP;
 )SRC";
-        // wrap bases are declared after the bodies are generated (we need to know which thresholds occur)
+        // per-lane slots of the row loads: chunk t = i * NTHREADS + tid of the NR x CH16 chunks of an iteration
+        for (int i = 0; i < g.nld; ++i) {
+            o << "    const int lt" << i << " = " << i << " * NTHREADS + tid, lrow" << i << " = lt" << i << " / CH16, lc" << i << " = lt" << i
+              << " - lrow" << i << " * CH16;\n";
+            const bool last_partial = (i == g.nld - 1) && (kNR * g.ch16 % kThreads != 0);
+            if (last_partial) {
+                o << "    const bool lvalid = lt" << i << " < NR * CH16;\n";
+                o << "    const u32 goff" << i << " = lvalid ? (u32)(lrow" << i << " * (Q * 8) + lc" << i << " * 16) : 0x80000000u;\n";
+                o << "    const long long nrel" << i << " = lvalid ? (long long)(lrow" << i << " * Q + lc" << i << " * 2) : -(1ll << 40);\n";
+            } else {
+                o << "    const u32 goff" << i << " = (u32)(lrow" << i << " * (Q * 8) + lc" << i << " * 16);\n";
+                o << "    const long long nrel" << i << " = lrow" << i << " * Q + lc" << i << " * 2;\n";
+            }
+            o << "    const u32 loff" << i << " = ring + (u32)(lrow" << i << " * PB + lc" << i << " * 16);\n";
+        }
+        for (int set = 0; set < P; ++set)
+            for (int i = 0; i < g.nld; ++i) o << "    u32x4 pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
+
+        std::vector<Unit> half[2];
+        split_units(half);
         std::ostringstream bodies;
         std::vector<int> thetas;
-        for (int km = 0; km < g.period; ++km) {
+        for (int km = 0; km < P; ++km) {
             bodies << "        // ------------------------------------------------------------ ring phase " << km << "\n        {\n";
-            // 1. request the rows of iteration k + 2
-            const int sb = (kNR * (km + 2) + g.a_hi - g.a_lo) % g.ms;
-            bodies << "#pragma unroll 1\n        for (int jj = 0; jj < 4; ++jj) {\n            int sl = " << sb
-                   << " + wave + 4 * jj;\n            if (sl >= MS) sl -= MS;\n            load_row((k + 2) * NR - ALO + wave + 4 * jj, (u32)sl * PB);\n        }\n";
-            // 2. stage A
+            // 1. request the rows of iteration k + P
+            emit_load_iter(bodies, km, "k + " + std::to_string(P));
+            // 2. stage A: this wave set's half of the units
             bodies << "        double";
             for (int i = 0; i < g.c; ++i) bodies << (i ? ", " : " ") << "acc" << i;
-            bodies << ";\n";
-            emit_stage_a(bodies, km, &thetas);
-            // 3. everyone is done reading the Delta buffer of the previous iteration
-            bodies << "        asm volatile(\"s_barrier\" ::: \"memory\");\n";
+            bodies << ";\n        if (hs == 0) {\n";
+            emit_stage_a(bodies, km, half[0], &thetas);
+            bodies << "        } else {\n";
+            emit_stage_a(bodies, km, half[1], &thetas);
+            bodies << "        }\n";
+            // 3. everyone is done reading the Delta buffers of the previous iteration
+            if (!(debug_ & 8)) bodies << "        asm volatile(\"s_barrier\" ::: \"memory\");\n";
             for (int i = 0; i < g.c; ++i)
-                bodies << "        *reinterpret_cast<LDS_AS double *>(dwr + " << 8 * i << ") = acc" << i << ";\n";
-            // 4. rows of iteration k + 1 landed (requested one iteration ago), Delta values written
-            bodies << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
-                   << "        else if (wave_has_b) asm volatile(\"s_waitcnt vmcnt(" << (kNR + 8) << ")\" ::: \"memory\");\n"
-                   << "        else asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");\n"
-                   << "        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n";
+                bodies << "        *(LDS_AS double *)(dwr + " << 8 * i << "u) = acc" << i << ";\n";
+            // 4. rows of iteration k + 1 (requested P - 1 iterations ago) into the ring
+            const int sb1 = ((kNR * ((km + 1) % P) + g.ofs - g.a_lo) % g.ms) * g.pb;
+            emit_write_iter(bodies, (km + 1) % P, sb1);
+            bodies << "        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n";
             // 5. stage B
-            const int slot_b = (kNR * km + g.a_hi) % g.ms;
+            const int slot_b = (kNR * km + g.ofs) % g.ms;
             bodies << "        {\n        const long long nrow = s0 + (long long)k * (NR * Q);\n"
                    << "        const bool fast = (k + 1) * NR * (long long)Q + s0 <= s_end && nrow >= a.hw && nrow + NR * Q - 1 + a.hw < a.n_total;\n"
-                   << "        if (fast) {\n          if (tid < Q) {\n          const u32 yoff = ystart + (u32)k * (u32)(NR * Q * 8);\n";
+                   << "        if (fast) {\n          if (tid < Q" << ((debug_ & 16) ? " && false" : "") << ") {\n          const u32 yoff = ystart + (u32)k * (u32)(NR * Q * 8);\n";
             emit_stage_b(bodies, km);
-            bodies << "          }\n        } else {\n          irregular = 2;\n          asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+            bodies << "          }\n        } else {\n          irregular = " << P << ";\n"
                    << "          if (tid < Q) {\n#pragma unroll 1\n            for (int rr = 0; rr < NR; ++rr) {\n              int sl = " << slot_b
                    << " + rr;\n              if (sl >= MS) sl -= MS;\n"
                    << "              const double xr = *reinterpret_cast<const double *>(smem + sl * PB + (HB + tid) * 8);\n"
-                   << "              const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + rr * DPB + tid * 8);\n"
+                   << "              const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + rr * DPB + tid * 8) +\n"
+                   << "                                *reinterpret_cast<const double *>(smem + RING_BYTES + DBYTES + rr * DPB + tid * 8);\n"
                    << "              const int m = k * NR + rr;\n              const long long n = s0 + (long long)m * Q + tid;\n"
-                   << "              if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);\n              S += dr;\n            }\n          }\n        }\n        }\n";
+                   << "              if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);\n"
+                   << "              S += dr;\n            }\n          }\n        }\n        }\n";
             bodies << "        }\n";
             bodies << "        if (++k >= n_iter) break;\n";
         }
         std::sort(thetas.begin(), thetas.end());
         for (int th : thetas) o << "    const u32 B1w" << th << " = B1 - (r >= " << th << " ? (u32)RING_BYTES : 0u);\n";
-        o << R"SRC(    const u32 dwr = dbuf + r * DPB + l * (CC * 8);
+        o << R"SRC(    const u32 dwr = dbuf + hs * DBYTES + r * DPB + l * (CC * 8);
     // stage-B lane: residue tid
     const u32 xb0 = ring + (HB + tid) * 8, xb1 = xb0 + HSTEP;
     const u32 db = dbuf + tid * 8;
     const u32 ystart = (u32)((s0 - a.out_first) * 8) + (u32)tid * 8u;
-    const bool wave_has_b = wave * 64 < Q;
-    int k = 0;
-    if (n_iter > 0) {
-    while (true) {
 )SRC";
+        // rows of iterations 1 .. P-1 are on their way before the loop starts
+        for (int set = 1; set < P; ++set) emit_load_iter(o, set, std::to_string(set));
+        o << "    int k = 0;\n    while (true) {\n";
         o << bodies.str();
-        o << R"SRC(    }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-)SRC";
+        o << "    }\n}\n";
         return o.str();
     }
 
    private:
     const Geom &g_;
     int batch_;
+    int debug_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------- code objects
