@@ -160,7 +160,7 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     g->hs = g->ms / 2;
     g->ring_bytes = g->ms * g->pb;
     g->d_bytes = kNR * g->dpb;
-    g->lds_total = g->ring_bytes + 2 * g->d_bytes;
+    g->lds_total = g->ring_bytes + g->d_bytes;
     g->ch16 = g->pb / 16;
     g->nld = (kNR * g->ch16 + kThreads - 1) / kThreads;
     if (g->lds_total > kLdsLimit) return false;
@@ -250,52 +250,53 @@ class Emitter {
         }
     }
 
-    // Stage A of ring phase km: acc[i] = Delta of this lane's C outputs
-    void emit_stage_a(std::ostringstream &o, int km, const std::vector<Unit> &units, std::vector<int> *thetas) const {
+    // Stage A of ring phase km for outputs [i0, i1) of this lane's C: acc<i> = their Delta
+    void emit_stage_a(std::ostringstream &o, int km, int i0, int i1, std::vector<int> *thetas) const {
         std::vector<Read> reads;
         std::vector<std::string> compute;
-        const int c = g_.c;
         bool first = true;
         int tcount = 0;
-        for (const Unit &u : units) {
+        for (const Unit &u : g_.units) {
             const char *sg = u.sign > 0 ? "+" : "-";
             const int b_hi = u.b_lo + u.width - 1;
             const int base_col = g_.hb - b_hi;  // element 0 of the unit for output 0 (lane part l*C is in the base)
             const int first_read = static_cast<int>(reads.size());
-            const int n_el = c + u.width - 1;
+            // elements j in [i0, i1 + width - 1): output i sums elements i .. i + width - 1
+            const int n_el = (i1 - i0) + u.width - 1;
             for (int j = 0; j < n_el; ++j) {
-                reads.push_back(tap_address(km, u.a, base_col + j, thetas));
+                reads.push_back(tap_address(km, u.a, base_col + i0 + j, thetas));
                 compute.push_back("");
             }
-            auto e = [&](int j) { return "ea" + std::to_string(first_read + j); };
+            auto e = [&](int j) { return "ea" + std::to_string(first_read + j); };  // j relative to i0
             if (u.width == 1) {
-                for (int i = 0; i < c; ++i) {
+                for (int i = i0; i < i1; ++i) {
                     std::ostringstream s;
-                    if (first) s << "        acc" << i << " = " << (u.sign > 0 ? "" : "-") << e(i) << ";\n";
-                    else s << "        acc" << i << " " << sg << "= " << e(i) << ";\n";
-                    compute[first_read + i] = s.str();
+                    if (first) s << "        acc" << i << " = " << (u.sign > 0 ? "" : "-") << e(i - i0) << ";\n";
+                    else s << "        acc" << i << " " << sg << "= " << e(i - i0) << ";\n";
+                    compute[first_read + (i - i0)] = s.str();
                 }
             } else {
-                // sliding sum: T_0 after element w-1, T_i after element i+w-1
+                // sliding sum: T_i0 after element w-1, T_i after element (i - i0) + w - 1
                 const std::string t = "tw" + std::to_string(tcount++);
-                for (int i = 0; i < c; ++i) {
+                for (int i = i0; i < i1; ++i) {
                     std::ostringstream s;
-                    if (i == 0) {
+                    const int ii = i - i0;
+                    if (ii == 0) {
                         s << "        double " << t << " = " << e(0);
                         for (int j = 1; j < u.width; ++j) s << " + " << e(j);
                         s << ";\n";
                     } else {
-                        s << "        " << t << " += " << e(i + u.width - 1) << " - " << e(i - 1) << ";\n";
+                        s << "        " << t << " += " << e(ii + u.width - 1) << " - " << e(ii - 1) << ";\n";
                     }
                     if (first) s << "        acc" << i << " = " << (u.sign > 0 ? "" : "-") << t << ";\n";
                     else s << "        acc" << i << " " << sg << "= " << t << ";\n";
-                    compute[first_read + i + u.width - 1] = s.str();
+                    compute[first_read + ii + u.width - 1] = s.str();
                 }
             }
             first = false;
         }
-        if ((debug_ & 1) || units.empty()) {
-            for (int i = 0; i < c; ++i) o << "        acc" << i << " = 0.0;\n";
+        if (debug_ & 1) {
+            for (int i = i0; i < i1; ++i) o << "        acc" << i << " = 0.0;\n";
             return;
         }
         emit_pipeline(o, "ea", reads, compute);
@@ -318,29 +319,15 @@ class Emitter {
             reads.push_back(x);
             compute.push_back("");
             reads.push_back({"db", r * g_.dpb});
-            compute.push_back("");
-            reads.push_back({"db", r * g_.dpb + g_.d_bytes});
             std::ostringstream s;
-            const int ix = 3 * r;
+            const int ix = 2 * r;
             s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n";
             if (debug_ & 2) s << "          asm volatile(\"\" :: \"v\"(yv));\n";
             else s << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n";
-            s << "          S += eb" << ix + 1 << " + eb" << ix + 2 << "; }\n";
+            s << "          S += eb" << ix + 1 << "; }\n";
             compute.push_back(s.str());
         }
-        emit_pipeline(o, "eb", reads, compute, 6);
-    }
-
-    // the units dealt over the two wave sets, balanced by LDS reads
-    void split_units(std::vector<Unit> (&half)[2]) const {
-        std::vector<Unit> sorted = g_.units;
-        std::stable_sort(sorted.begin(), sorted.end(), [](const Unit &x, const Unit &y) { return x.width > y.width; });
-        int load[2] = {0, 0};
-        for (const Unit &u : sorted) {
-            const int h = load[1] < load[0] ? 1 : 0;
-            half[h].push_back(u);
-            load[h] += g_.c + u.width - 1;
-        }
+        emit_pipeline(o, "eb", reads, compute, 6);  // three rows per batch
     }
 
     // Request the NR rows of iteration `kk` (an expression) into register set `set`.  The loads are inline asm and
@@ -527,8 +514,8 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
         for (int set = 0; set < P; ++set)
             for (int i = 0; i < g.nld; ++i) o << "    u32x4 pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
 
-        std::vector<Unit> half[2];
-        split_units(half);
+        // wave set 0 (which also runs stage B) takes the smaller half of each lane's C outputs
+        const int c_split = g.c / 2;
         std::ostringstream bodies;
         std::vector<int> thetas;
         for (int km = 0; km < P; ++km) {
@@ -539,14 +526,19 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
             bodies << "        double";
             for (int i = 0; i < g.c; ++i) bodies << (i ? ", " : " ") << "acc" << i;
             bodies << ";\n        if (hs == 0) {\n";
-            emit_stage_a(bodies, km, half[0], &thetas);
+            emit_stage_a(bodies, km, 0, c_split, &thetas);
             bodies << "        } else {\n";
-            emit_stage_a(bodies, km, half[1], &thetas);
+            emit_stage_a(bodies, km, c_split, g.c, &thetas);
             bodies << "        }\n";
-            // 3. everyone is done reading the Delta buffers of the previous iteration
+            // 3. everyone is done reading the Delta buffer of the previous iteration
             if (!(debug_ & 8)) bodies << "        asm volatile(\"s_barrier\" ::: \"memory\");\n";
-            for (int i = 0; i < g.c; ++i)
-                bodies << "        *(LDS_AS double *)(dwr + " << 8 * i << "u) = acc" << i << ";\n";
+            bodies << "        if (hs == 0) {\n";
+            for (int i = 0; i < c_split; ++i)
+                bodies << "            *(LDS_AS double *)(dwr + " << 8 * i << "u) = acc" << i << ";\n";
+            bodies << "        } else {\n";
+            for (int i = c_split; i < g.c; ++i)
+                bodies << "            *(LDS_AS double *)(dwr + " << 8 * i << "u) = acc" << i << ";\n";
+            bodies << "        }\n";
             // 4. rows of iteration k + 1 (requested P - 1 iterations ago) into the ring
             const int sb1 = ((kNR * ((km + 1) % P) + g.ofs - g.a_lo) % g.ms) * g.pb;
             emit_write_iter(bodies, (km + 1) % P, sb1);
@@ -561,8 +553,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
                    << "          if (tid < Q) {\n#pragma unroll 1\n            for (int rr = 0; rr < NR; ++rr) {\n              int sl = " << slot_b
                    << " + rr;\n              if (sl >= MS) sl -= MS;\n"
                    << "              const double xr = *reinterpret_cast<const double *>(smem + sl * PB + (HB + tid) * 8);\n"
-                   << "              const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + rr * DPB + tid * 8) +\n"
-                   << "                                *reinterpret_cast<const double *>(smem + RING_BYTES + DBYTES + rr * DPB + tid * 8);\n"
+                   << "              const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + rr * DPB + tid * 8);\n"
                    << "              const int m = k * NR + rr;\n              const long long n = s0 + (long long)m * Q + tid;\n"
                    << "              if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);\n"
                    << "              S += dr;\n            }\n          }\n        }\n        }\n";
@@ -571,7 +562,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
         }
         std::sort(thetas.begin(), thetas.end());
         for (int th : thetas) o << "    const u32 B1w" << th << " = B1 - (r >= " << th << " ? (u32)RING_BYTES : 0u);\n";
-        o << R"SRC(    const u32 dwr = dbuf + hs * DBYTES + r * DPB + l * (CC * 8);
+        o << R"SRC(    const u32 dwr = dbuf + r * DPB + l * (CC * 8);
     // stage-B lane: residue tid
     const u32 xb0 = ring + (HB + tid) * 8, xb1 = xb0 + HSTEP;
     const u32 db = dbuf + tid * 8;
