@@ -15,13 +15,17 @@
 //     T_0 = e_0 + .. + e_{w-1},  T_i = T_{i-1} + e_{i+w-1} - e_{i-1}.  BASELINE geometry (28 delta taps =
 //     14 single taps + two 7-wide teeth): 17.1 LDS reads and 20.7 float64 adds per output instead of 28 + 28
 //     (+ 17 address adds + table traffic) in the phase-major kernel.
-//   * Stage B (outputs).  Thread = residue (coalesced 8-byte stores as before) walks the NR rows of the
-//     iteration: y = x - S / n_taps, S += Delta.  The Delta values change hands through an LDS buffer; S stays
-//     in a register for the whole stretch, so there is no chain between row groups at all.
-//   * The delta units are split between two wave sets (8 waves per workgroup, one workgroup per CU): both sets
-//     work on the same NR rows, each on half of the taps, and stage B adds the two partial Deltas.  Two waves
-//     per SIMD let one wave's LDS issue overlap the other's float64 adds (first version, one set of four waves:
-//     5.6 ms of pure issue time for 256 ch x 10 M; the ring of a second workgroup does not fit the LDS).
+//   * Stage B (outputs) runs ONE ITERATION BEHIND stage A, on the first three waves, before they start their
+//     (lighter) share of stage A.  Thread = residue (coalesced 8-byte stores as before) walks the NR rows of the
+//     iteration: y = x - S / n_taps, S += Delta.  The Delta values change hands through a double-buffered LDS
+//     array; S stays in a register for the whole stretch, so there is no chain between row groups at all; the
+//     stores have a whole stage A to drain before the next barrier (one barrier per iteration).  (Stage B on
+//     three waves of its own -- 11 waves -- caps the kernel at 168 VGPRs and hipcc then spills the prefetch
+//     registers, whose loads are in flight: not an option.)
+//   * Stage A runs on two wave sets (8 waves, one workgroup per CU: the ring of a second workgroup does not fit
+//     the LDS): both sets work on the same NR rows, each on half of every lane's C outputs.  Two waves per SIMD
+//     let one wave's LDS issue overlap the other's float64 adds (first version, one set of four waves: 5.6 ms of
+//     pure issue time for 256 ch x 10 M).
 //   * Rows are requested P = 4 iterations ahead into registers (16-byte coalesced buffer loads, ~90 KB in
 //     flight per CU: the first version staged rows by LDS-DMA two iterations ahead, 48 KB in flight, and its
 //     read stream alone ran at 4.1 TB/s) and copied into the ring one iteration ahead (ds_write_b128).  Ring
@@ -56,7 +60,7 @@ namespace parrm_filter {
 namespace {
 
 constexpr int kNR = 16;       // rows per iteration (4 waves x 4 rows)
-constexpr int kThreads = 512;  // two wave sets of four waves
+constexpr int kAThreads = 512;  // stage A: two wave sets of four waves (stage B: ceil(q / 64) more waves)
 constexpr int kLdsLimit = 160 * 1024;
 
 struct Unit {  // one delta element: `width` adjacent taps of one sign in row m - a, offsets b_lo .. b_lo + width - 1
@@ -69,6 +73,7 @@ struct Run {   // full-tap run for the per-stretch initialisation
 struct Geom {
     int q = 0, c = 0, hb = 0, ncol = 0, pitch = 0, ms = 0, a_lo = 0, a_hi = 0;
     int pb = 0, dpb = 0, ring_bytes = 0, lds_total = 0, hs = 0, period = 0;
+    int b_threads = 0, threads = 0;  // stage-B lanes (whole waves >= q); workgroup size
     int ofs = 0, ch16 = 0, d_bytes = 0, nld = 0;  // slot of row m: (m + ofs) mod ms; 16-byte chunks per row; one Delta buffer; loads per lane
     int n_taps = 0;
     std::vector<Unit> units;
@@ -160,9 +165,11 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     g->hs = g->ms / 2;
     g->ring_bytes = g->ms * g->pb;
     g->d_bytes = kNR * g->dpb;
-    g->lds_total = g->ring_bytes + g->d_bytes;
+    g->lds_total = g->ring_bytes + 2 * g->d_bytes;  // the Delta buffer is double-buffered
+    g->b_threads = (g->q + 63) / 64 * 64;
+    g->threads = kAThreads;  // stage B runs on the first b_threads / 64 waves, in front of their stage A
     g->ch16 = g->pb / 16;
-    g->nld = (kNR * g->ch16 + kThreads - 1) / kThreads;
+    g->nld = (kNR * g->ch16 + kAThreads - 1) / kAThreads;
     if (g->lds_total > kLdsLimit) return false;
     if (g->hs * g->pb + g->pb > 65000) return false;         // immediates of ds_read are 16 bits
     if (g->ofs - g->a_lo + kNR > g->ms) return false;         // prologue fill must not wrap
@@ -198,6 +205,8 @@ class Emitter {
                 r.imm = (slot0 - g_.hs) * g_.pb + col * 8;
             }
         } else {
+            // lanes whose row wraps past the ring's end read RING_BYTES lower: one compare + select per unit (the
+            // emitter declares the base in front of the unit's first read), not a register held for the whole kernel
             const int theta = g_.ms - slot0;
             if (std::find(thetas->begin(), thetas->end(), theta) == thetas->end()) thetas->push_back(theta);
             r.base = "B1w" + std::to_string(theta);
@@ -251,7 +260,8 @@ class Emitter {
     }
 
     // Stage A of ring phase km for outputs [i0, i1) of this lane's C: acc<i> = their Delta
-    void emit_stage_a(std::ostringstream &o, int km, int i0, int i1, std::vector<int> *thetas) const {
+    void emit_stage_a(std::ostringstream &o, int km, int i0, int i1) const {
+        std::vector<int> local_thetas, *thetas = &local_thetas;
         std::vector<Read> reads;
         std::vector<std::string> compute;
         bool first = true;
@@ -299,6 +309,7 @@ class Emitter {
             for (int i = i0; i < i1; ++i) o << "        acc" << i << " = 0.0;\n";
             return;
         }
+        for (int th : local_thetas) o << "        const u32 B1w" << th << " = B1 - (r >= " << th << " ? (u32)RING_BYTES : 0u);\n";
         emit_pipeline(o, "ea", reads, compute);
     }
 
@@ -318,7 +329,7 @@ class Emitter {
             }
             reads.push_back(x);
             compute.push_back("");
-            reads.push_back({"db", r * g_.dpb});
+            reads.push_back({"dbk", r * g_.dpb});
             std::ostringstream s;
             const int ix = 2 * r;
             s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n";
@@ -333,16 +344,20 @@ class Emitter {
     // Request the NR rows of iteration `kk` (an expression) into register set `set`.  The loads are inline asm and
     // the wait before the set is copied into the ring is a COUNTED vmcnt written by hand (emit_write_iter): with
     // compiler-visible loads hipcc drained the queue (vmcnt(0)) once per ring period, i.e. gave up the whole
-    // prefetch depth every P iterations.  Vector memory operations retire in issue order, so "at most N
-    // outstanding" with N = everything issued after the set's loads on the regular path (the loads and output
-    // stores of the P-1 iterations since) means the set has landed; any path that issues a different number of
-    // operations (rows at the ends of the window, edge outputs) raises `irregular` and the next P waits drain.
+    // prefetch depth every P iterations.  Loads retire in issue order among themselves, so "at most N
+    // outstanding" with N = the loads issued after the set's own on the regular path (those of the P-1 iterations
+    // since) means the set has landed; a path that issues fewer (rows at the ends of the window are fetched by
+    // compiler-visible loads) raises `irregular` and the next P waits drain.
     void emit_load_iter(std::ostringstream &o, int set, const std::string &kk) const {
         if (debug_ & 4) {
             for (int i = 0; i < g_.nld; ++i) o << "        pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
             return;
         }
-        o << "        {\n        const long long lo = s0 + (long long)(NR * (" << kk << ") - ALO) * Q - HB;\n"
+        // (nothing is requested beyond the stretch's last iteration: a load that lands after the loop would write
+        // into registers the compiler has reused by then -- it did, and corrupted the running sums of the last
+        // rows of a few stretches per launch; `irregular` makes the waits of those last iterations drain)
+        o << "        if ((" << kk << ") >= n_iter) {\n            irregular = " << g_.period << ";\n        } else {\n"
+          << "        const long long lo = s0 + (long long)(NR * (" << kk << ") - ALO) * Q - HB;\n"
           << "        if (lo >= lim_lo && lo + (NR - 1) * Q + NCOL <= lim_hi) {\n"
           << "            const u32 soff = (u32)((lo - a.buf_first) * 8);\n            asm volatile(";
         const int n = g_.nld;
@@ -355,7 +370,7 @@ class Emitter {
         o << ", \"s\"(xdesc), \"s\"(soff) : \"memory\");\n";
         o << "        } else {\n            irregular = " << g_.period << ";\n";
         for (int i = 0; i < g_.nld; ++i)
-            o << "            pf" << set << "_" << i << " = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, lo + nrel" << i << ");\n";
+            o << "            pf" << set << "_" << i << " = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, (goff" << i << " >> 31) ? -(1ll << 40) : lo + (long long)(goff" << i << " >> 3));\n";
         // (the empty asm makes the compiler wait for these loads HERE: left pending they would put its own
         // vmcnt(0) in front of the ring copy of every iteration that merges with this path)
         for (int i = 0; i < g_.nld; ++i) o << "            asm volatile(\"\" : \"+v\"(pf" << set << "_" << i << "));\n";
@@ -364,11 +379,14 @@ class Emitter {
 
     // copy register set `set` into the ring slots that start at byte offset `sb`
     void emit_write_iter(std::ostringstream &o, int set, int sb) const {
-        const bool partial = kNR * g_.ch16 % kThreads != 0;
+        const bool partial = kNR * g_.ch16 % kAThreads != 0;
         const int younger_loads = (g_.period - 1) * g_.nld;
-        const int younger_all = std::min(63, (g_.period - 1) * (g_.nld + kNR));
+        // Only LOADS are counted, on the stage-B waves too: their output stores sit between the loads in issue
+        // order, but a count that includes them (57 = 9 loads + 48 stores) is satisfied as soon as the stores have
+        // retired, whatever the loads are doing -- stores retire ahead of older loads often enough to corrupt a few
+        // stretches per launch (measured).  "At most 9 outstanding" can only be the 9 youngest loads, because loads
+        // retire in order among themselves; it merely makes those waves wait for stores issued a whole stage A ago.
         o << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
-          << "        else if (wave_has_b) asm volatile(\"s_waitcnt vmcnt(" << younger_all << ")\" ::: \"memory\");\n"
           << "        else asm volatile(\"s_waitcnt vmcnt(" << std::min(63, younger_loads) << ")\" ::: \"memory\");\n";
         for (int i = 0; i < g_.nld; ++i) {
             o << "        ";
@@ -389,7 +407,7 @@ class Emitter {
           << "\n#define NCOL " << g.ncol << "\n#define PB " << g.pb << "\n#define DPB " << g.dpb << "\n#define AHI " << g.a_hi
           << "\n#define ALO (" << g.a_lo << ")\n#define OFS " << g.ofs << "\n#define RING_BYTES " << g.ring_bytes << "\n#define DBYTES " << g.d_bytes
           << "\n#define LDS_TOTAL " << g.lds_total << "\n#define HSTEP " << g.hs * g.pb << "\n#define CH16 " << g.ch16
-          << "\n#define PERIOD " << g.period << "\n#define NTHREADS " << kThreads << "\n#define N_RUNS " << g.runs.size() << "\n";
+          << "\n#define PERIOD " << g.period << "\n#define ATHREADS " << kAThreads << "\n#define BTHREADS " << g.b_threads << "\n#define NTHREADS " << g.threads << "\n#define N_RUNS " << g.runs.size() << "\n";
         o << "__device__ const int RUN_A[N_RUNS] = {";
         for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].a;
         o << "};\n__device__ const int RUN_BLO[N_RUNS] = {";
@@ -466,11 +484,13 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
         xdesc.z = __builtin_amdgcn_readfirstlane((u32)(a.buf_len * 8));
         xdesc.w = 0x00020000u;
     }
-    // > 0: the counted vmcnt of the ring copy does not hold (fewer operations were issued lately than the regular
-    // path issues: the first P-1 iterations of a stretch have no output stores behind them yet, rows at the ends
-    // of the window are fetched differently, edge outputs are stored differently) -> that wait drains the queue
-    int irregular = PERIOD - 1;
-    const bool wave_has_b = __builtin_amdgcn_readfirstlane(tid & ~63) < Q;
+    // > 0: the counted vmcnt of the ring copy does not hold (rows at the ends of the window are fetched by a
+    // different number of operations than the regular path issues) -> that wait drains the queue
+    int irregular = 0;
+    // every wave computes tap sums (stage A); the first ceil(Q / 64) waves also turn the tap sums of the PREVIOUS
+    // iteration into outputs (stage B) before they start on this one
+    const bool wave_has_b = __builtin_amdgcn_readfirstlane(tid) < BTHREADS;
+    const int rho = tid;  // stage-B lane: residue
 
     // prologue: rows [-AHI, -ALO + NR) -> slots OFS - AHI .. (everything iteration 0 reads), 16-byte chunks
 #pragma unroll 1
@@ -482,10 +502,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     __syncthreads();
     // running tap sum of row 0, evaluated tap by tap (thread = residue)
     double S = 0.0;
-    if (tid < Q) {
+    if (rho < Q) {
 #pragma unroll 1
         for (int rr = 0; rr < N_RUNS; ++rr) {
-            const double *rowp = reinterpret_cast<const double *>(smem + (OFS - RUN_A[rr]) * PB) + (HB + tid);
+            const double *rowp = reinterpret_cast<const double *>(smem + (OFS - RUN_A[rr]) * PB) + (HB + rho);
             for (int b = RUN_BLO[rr]; b <= RUN_BHI[rr]; ++b) S += rowp[-b];
         }
     }
@@ -498,81 +518,88 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
 )SRC";
         // per-lane slots of the row loads: chunk t = i * NTHREADS + tid of the NR x CH16 chunks of an iteration
         for (int i = 0; i < g.nld; ++i) {
-            o << "    const int lt" << i << " = " << i << " * NTHREADS + tid, lrow" << i << " = lt" << i << " / CH16, lc" << i << " = lt" << i
+            o << "    const int lt" << i << " = " << i << " * ATHREADS + tid, lrow" << i << " = lt" << i << " / CH16, lc" << i << " = lt" << i
               << " - lrow" << i << " * CH16;\n";
-            const bool last_partial = (i == g.nld - 1) && (kNR * g.ch16 % kThreads != 0);
+            const bool last_partial = (i == g.nld - 1) && (kNR * g.ch16 % kAThreads != 0);
             if (last_partial) {
                 o << "    const bool lvalid = lt" << i << " < NR * CH16;\n";
                 o << "    const u32 goff" << i << " = lvalid ? (u32)(lrow" << i << " * (Q * 8) + lc" << i << " * 16) : 0x80000000u;\n";
-                o << "    const long long nrel" << i << " = lvalid ? (long long)(lrow" << i << " * Q + lc" << i << " * 2) : -(1ll << 40);\n";
+
             } else {
                 o << "    const u32 goff" << i << " = (u32)(lrow" << i << " * (Q * 8) + lc" << i << " * 16);\n";
-                o << "    const long long nrel" << i << " = lrow" << i << " * Q + lc" << i << " * 2;\n";
+
             }
             o << "    const u32 loff" << i << " = ring + (u32)(lrow" << i << " * PB + lc" << i << " * 16);\n";
         }
         for (int set = 0; set < P; ++set)
             for (int i = 0; i < g.nld; ++i) o << "    u32x4 pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
 
-        // wave set 0 (which also runs stage B) takes the smaller half of each lane's C outputs
-        const int c_split = g.c / 2;
+        // the two stage-A wave sets split each lane's C outputs; set 0 holds the stage-B waves and takes fewer
+        int c_split = (g.c * 4 + 5) / 11;  // 4 of 11
+        if (const char *e = getenv("PARRM_COMB_SPLIT")) c_split = atoi(e);
+        c_split = std::min(g.c - 1, std::max(1, c_split));
         std::ostringstream bodies;
-        std::vector<int> thetas;
         for (int km = 0; km < P; ++km) {
+            const int kmb = (km + P - 1) % P;  // ring phase of iteration k - 1
             bodies << "        // ------------------------------------------------------------ ring phase " << km << "\n        {\n";
+            // 0. stage B of iteration k - 1 (its stores then have the whole of stage A to drain)
+            bodies << "        if (wave_has_b && k > 0) {\n        const int kk = k - 1;\n"
+                   << "        const long long nrow = s0 + (long long)kk * (NR * Q);\n"
+                   << "        const bool fast = (kk + 1) * NR * (long long)Q + s0 <= s_end && nrow >= a.hw && nrow + NR * Q - 1 + a.hw < a.n_total;\n"
+                   << "        if (fast) {\n          if (rho < Q" << ((debug_ & 16) ? " && false" : "") << ") {\n"
+                   << "          const u32 yoff = ystart + (u32)kk * (u32)(NR * Q * 8);\n          const u32 dbk = db + (u32)(kk & 1) * DBYTES;\n";
+            emit_stage_b(bodies, kmb);
+            bodies << "          }\n        } else {\n          stage_b_generic(kk);\n        }\n        }\n";
             // 1. request the rows of iteration k + P
             emit_load_iter(bodies, km, "k + " + std::to_string(P));
-            // 2. stage A: this wave set's half of the units
+            // 2. stage A: this wave set's part of the lane's outputs
             bodies << "        double";
             for (int i = 0; i < g.c; ++i) bodies << (i ? ", " : " ") << "acc" << i;
             bodies << ";\n        if (hs == 0) {\n";
-            emit_stage_a(bodies, km, 0, c_split, &thetas);
+            emit_stage_a(bodies, km, 0, c_split);
             bodies << "        } else {\n";
-            emit_stage_a(bodies, km, c_split, g.c, &thetas);
+            emit_stage_a(bodies, km, c_split, g.c);
             bodies << "        }\n";
-            // 3. everyone is done reading the Delta buffer of the previous iteration
-            if (!(debug_ & 8)) bodies << "        asm volatile(\"s_barrier\" ::: \"memory\");\n";
-            bodies << "        if (hs == 0) {\n";
+            // 3. Delta values into buffer k & 1 (stage B of iteration k - 1 read the other one)
+            bodies << "        const u32 dw = dwr + (u32)(k & 1) * DBYTES;\n        if (hs == 0) {\n";
             for (int i = 0; i < c_split; ++i)
-                bodies << "            *(LDS_AS double *)(dwr + " << 8 * i << "u) = acc" << i << ";\n";
+                bodies << "            *(LDS_AS double *)(dw + " << 8 * i << "u) = acc" << i << ";\n";
             bodies << "        } else {\n";
             for (int i = c_split; i < g.c; ++i)
-                bodies << "            *(LDS_AS double *)(dwr + " << 8 * i << "u) = acc" << i << ";\n";
+                bodies << "            *(LDS_AS double *)(dw + " << 8 * i << "u) = acc" << i << ";\n";
             bodies << "        }\n";
             // 4. rows of iteration k + 1 (requested P - 1 iterations ago) into the ring
             const int sb1 = ((kNR * ((km + 1) % P) + g.ofs - g.a_lo) % g.ms) * g.pb;
             emit_write_iter(bodies, (km + 1) % P, sb1);
-            bodies << "        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n";
-            // 5. stage B
-            const int slot_b = (kNR * km + g.ofs) % g.ms;
-            bodies << "        {\n        const long long nrow = s0 + (long long)k * (NR * Q);\n"
-                   << "        const bool fast = (k + 1) * NR * (long long)Q + s0 <= s_end && nrow >= a.hw && nrow + NR * Q - 1 + a.hw < a.n_total;\n"
-                   << "        if (fast) {\n          if (tid < Q" << ((debug_ & 16) ? " && false" : "") << ") {\n          const u32 yoff = ystart + (u32)k * (u32)(NR * Q * 8);\n";
-            emit_stage_b(bodies, km);
-            bodies << "          }\n        } else {\n          irregular = " << P << ";\n"
-                   << "          if (tid < Q) {\n#pragma unroll 1\n            for (int rr = 0; rr < NR; ++rr) {\n              int sl = " << slot_b
-                   << " + rr;\n              if (sl >= MS) sl -= MS;\n"
-                   << "              const double xr = *reinterpret_cast<const double *>(smem + sl * PB + (HB + tid) * 8);\n"
-                   << "              const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + rr * DPB + tid * 8);\n"
-                   << "              const int m = k * NR + rr;\n              const long long n = s0 + (long long)m * Q + tid;\n"
-                   << "              if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);\n"
-                   << "              S += dr;\n            }\n          }\n        }\n        }\n";
-            bodies << "        }\n";
+            bodies << "        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n        }\n";
             bodies << "        if (++k >= n_iter) break;\n";
         }
-        std::sort(thetas.begin(), thetas.end());
-        for (int th : thetas) o << "    const u32 B1w" << th << " = B1 - (r >= " << th << " ? (u32)RING_BYTES : 0u);\n";
         o << R"SRC(    const u32 dwr = dbuf + r * DPB + l * (CC * 8);
-    // stage-B lane: residue tid
-    const u32 xb0 = ring + (HB + tid) * 8, xb1 = xb0 + HSTEP;
-    const u32 db = dbuf + tid * 8;
-    const u32 ystart = (u32)((s0 - a.out_first) * 8) + (u32)tid * 8u;
+    // stage-B lane
+    const u32 xb0 = ring + (HB + rho) * 8, xb1 = xb0 + HSTEP;
+    const u32 db = dbuf + rho * 8;
+    const u32 ystart = (u32)((s0 - a.out_first) * 8) + (u32)rho * 8u;
+    // stage B of iteration kk for rows that touch an end of the recording or of the stretch (and the last iteration)
+    auto stage_b_generic = [&](int kk) {
+        if (rho < Q) {
+#pragma unroll 1
+            for (int rr = 0; rr < NR; ++rr) {
+                const int sl = (NR * kk + OFS + rr) % MS;
+                const double xr = *reinterpret_cast<const double *>(smem + sl * PB + (HB + rho) * 8);
+                const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + (kk & 1) * DBYTES + rr * DPB + rho * 8);
+                const int m = kk * NR + rr;
+                const long long n = s0 + (long long)m * Q + rho;
+                if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);
+                S += dr;
+            }
+        }
+    };
 )SRC";
         // rows of iterations 1 .. P-1 are on their way before the loop starts
         for (int set = 1; set < P; ++set) emit_load_iter(o, set, std::to_string(set));
         o << "    int k = 0;\n    while (true) {\n";
         o << bodies.str();
-        o << "    }\n}\n";
+        o << "    }\n    if (wave_has_b) stage_b_generic(n_iter - 1);\n}\n";
         return o.str();
     }
 
@@ -809,7 +836,7 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     ca.hw = a.hw;
     size_t sz = sizeof(ca);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ca, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    PARRM_HIP_CHECK(hipModuleLaunchKernel(k->func, static_cast<unsigned>(blocks), 1, 1, kThreads, 1, 1, 0, stream, nullptr, config));
+    PARRM_HIP_CHECK(hipModuleLaunchKernel(k->func, static_cast<unsigned>(blocks), 1, 1, static_cast<unsigned>(g.threads), 1, 1, 0, stream, nullptr, config));
     return PARRM_OK;
 }
 
