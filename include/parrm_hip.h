@@ -152,6 +152,11 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
  * it generates the kernel for a filter array and writes <out_dir>/comb_<hash>.hsaco (and its source, whose
  * path is returned in source_path when that is not NULL).  `stride` 0 = the stride a plan would choose.
  * PARRM_ERR_INVALID when the generated form does not take this filter (such filters run the generic kernels). */
+/* Has this plan's generated kernel been used?  state: 0 = no launch large enough yet (or PARRM_COMB=0),
+ * 1 = generated, loaded, self-tested against the tap-by-tap kernel and in use for float64 launches,
+ * -1 = not available for this filter (message says why; the generic kernels run instead). */
+int parrm_filter_plan_generated(const parrm_filter_plan *plan, int *state, int *stride, char *message,
+                                size_t message_len);
 int parrm_filter_comb_precompile(const double *h_filter, int64_t filter_len, int64_t stride,
                                  const char *out_dir, char *source_path, size_t source_path_len);
 

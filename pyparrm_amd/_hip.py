@@ -34,6 +34,7 @@ SYMBOLS = (
     "parrm_filter_apply_block",
     "parrm_filter_host",
     "parrm_filter_comb_precompile",
+    "parrm_filter_plan_generated",
     "parrm_host_pin",
     "parrm_host_unpin",
     "parrm_absdiff_workspace_bytes",
@@ -145,6 +146,8 @@ def lib() -> C.CDLL:
         L.parrm_filter_plan_query.argtypes = [vp, C.POINTER(PlanInfo)]
         L.parrm_filter_plan_set_kernel.restype = i32
         L.parrm_filter_plan_set_kernel.argtypes = [vp, i32]
+        L.parrm_filter_plan_generated.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+        L.parrm_filter_comb_precompile.argtypes = [vp, i64, i64, C.c_char_p, C.c_char_p, C.c_size_t]
         L.parrm_filter_apply.restype = i32
         L.parrm_filter_apply.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
         L.parrm_filter_apply_window.restype = i32
@@ -305,6 +308,14 @@ class FilterPlan:
         check(lib().parrm_filter_plan_query(self._h, C.byref(out)), "parrm_filter_plan_query")
         return out
 
+    @property
+    def generated(self):
+        """(state, stride, message) of the per-filter generated kernel: state 1 = in use, 0 = not tried yet, -1 = unavailable."""
+        state, stride = C.c_int(0), C.c_int(0)
+        msg = C.create_string_buffer(512)
+        check(lib().parrm_filter_plan_generated(self._h, C.byref(state), C.byref(stride), msg, 512), "filter_plan_generated")
+        return state.value, stride.value, msg.value.decode(errors="replace")
+
     def set_kernel(self, kernel: int) -> None:
         check(lib().parrm_filter_plan_set_kernel(self._h, kernel), "parrm_filter_plan_set_kernel")
 
@@ -399,6 +410,19 @@ class FilterPlan:
 
 _PLAN_CACHE: dict = {}
 _PLAN_CACHE_SIZE = 16
+
+
+def precompile_filter_kernel(filt: np.ndarray, out_dir: str | None = None, stride: int = 0) -> str:
+    """Generate and compile (hipRTC; no GPU needed) the per-filter kernel of `filt` -- a filter array as
+    `PARRM.create_filter` makes them -- into `out_dir` (default: the in-tree `lib/kernels/`, which the library
+    searches before its user cache) and return the path of the generated source.  Raises `HipLibraryError`
+    when the generated form does not take the filter."""
+    out_dir = out_dir or os.path.join(os.path.dirname(library_path()), "kernels")
+    filt = np.ascontiguousarray(filt, dtype=np.float64)
+    buf = C.create_string_buffer(4096)
+    check(lib().parrm_filter_comb_precompile(filt.ctypes.data, filt.size, stride, out_dir.encode(), buf, 4096),
+          "filter_comb_precompile")
+    return buf.value.decode()
 
 
 def shared_filter_plan(filt: np.ndarray, device: int) -> FilterPlan:

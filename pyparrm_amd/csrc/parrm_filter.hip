@@ -295,24 +295,96 @@ __global__ void __launch_bounds__(256) filter_combine_kernel(FilterArgs a, const
 template <typename TI, typename TO>
 int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStream_t stream);
 
-// The generated kernel (parrm_filter_comb.hip) for this launch, or nullptr: float64 recordings, guarded phase
-// plans with q in [96, 256].  PARRM_COMB=0 turns it off, PARRM_COMB=force takes it for any size; otherwise a
+// The generated kernel (parrm_filter_comb.hip) for this launch, or nullptr: float64 recordings, comb filters
+// with a stride in [80, 176] whose delta taps sit within 12 residues of its multiples.  PARRM_COMB=0 turns it off, PARRM_COMB=force takes it for any size; otherwise a
 // launch must be large enough (2^25 samples) to be worth a possible hipRTC compile (seconds, once per filter
 // geometry: code objects are cached on disk).  A failure to generate, compile or load is remembered and the
 // launch falls back to filter_phase_kernel -- same results within the parity bar, never an error.
 std::mutex g_comb_mutex;
+
+// First use of a generated kernel: run it once on a small pseudo-random recording (a few stretches of a few ring
+// periods, both ends of the recording included) and compare with the tap-by-tap gather kernel.  The generator is
+// exercised by filters nobody has seen before (tap geometry is the caller's: create_filter's half-widths, omitted
+// samples, direction); a kernel that does not reproduce the direct evaluation is never used.  ~1 ms, once per plan.
+bool comb_self_test(const parrm_filter_plan *p) {
+    if (getenv("PARRM_COMB_NO_SELFTEST")) return true;
+    const int64_t n = 2 * p->hw + 6 * comb_reach(p->comb) + 12345, c = 2;
+    std::vector<double> h(static_cast<size_t>(c * n));
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    for (double &v : h) {  // xorshift, values in [-1, 1) with a full mantissa
+        st ^= st << 13;
+        st ^= st >> 7;
+        st ^= st << 17;
+        v = static_cast<double>(static_cast<int64_t>(st >> 11)) * (1.0 / 4503599627370496.0) - 1.0;
+    }
+    double *d = nullptr;
+    bool ok = false;
+    hipError_t e = hipMalloc(&d, static_cast<size_t>(3 * c * n) * sizeof(double));
+    if (e == hipSuccess) {
+        e = hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+        FilterArgs a{};
+        a.x = d;
+        a.n_chans = c;
+        a.plan_chans = c;
+        a.buf_first = 0;
+        a.buf_len = n;
+        a.out_first = 0;
+        a.out_len = n;
+        a.n_total = n;
+        a.ldx = n;
+        a.ldy = n;
+        fill_plan_args(p, &a);
+        FilterArgs b = a;
+        a.y = d + c * n;
+        b.y = d + 2 * c * n;
+        int rc = PARRM_OK;
+        if (e == hipSuccess) rc = launch_comb(p->comb, &a, nullptr);
+        if (e == hipSuccess && rc == PARRM_OK) rc = launch_main<double, double>(p, &b, PARRM_KERNEL_GATHER, nullptr);
+        std::vector<double> y1(h.size()), y2(h.size());
+        if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpy(y1.data(), a.y, y1.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpy(y2.data(), b.y, y2.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc == PARRM_OK) {
+            double worst = 0.0;
+            for (size_t i = 0; i < y1.size(); ++i) {
+                const double dd = std::fabs(y1[i] - y2[i]);
+                if (!(dd <= worst)) worst = dd;  // (NaN counts as a failure)
+            }
+            ok = worst <= 1e-11;  // samples are O(1): the direct evaluation rounds at ~1e-15
+            if (!ok) {
+                char msg[128];
+                snprintf(msg, sizeof msg, "self-test against the gather kernel failed (max |d| %.3e)", worst);
+                comb_set_error(p->comb, msg);
+            }
+        } else {
+            comb_set_error(p->comb, "self-test could not run");
+        }
+    } else {
+        comb_set_error(p->comb, "self-test: out of device memory");
+    }
+    if (d) (void)hipFree(d);
+    return ok;
+}
+
 const CombKernel *comb_for_launch(const parrm_filter_plan *p, const FilterArgs &a) {
     const char *env = getenv("PARRM_COMB");
     if (env && env[0] == '0') return nullptr;
     const bool force = env && env[0] == 'f';
     if (!force && a.plan_chans * a.out_len < (int64_t{1} << 25)) return nullptr;
-    if (p->phase.n_groups == 0 || p->phase.wrap || p->tap_mask.empty()) return nullptr;
+    if (p->tap_mask.empty()) return nullptr;
     std::lock_guard<std::mutex> lock(g_comb_mutex);
     if (p->comb_state == 0) {
-        p->comb = comb_generate(p->tap_mask, p->hw, p->phase.q);
+        const int64_t q = comb_search_stride(p->tap_mask, p->hw);
+        p->comb = q ? comb_generate(p->tap_mask, p->hw, q) : nullptr;
+        // Unless forced, only where it has clearly less LDS traffic than the phase-major kernel (whose figure is
+        // its number of delta taps): BASELINE geometry 17.8 reads per output against 28.
+        if (p->comb && !force && p->phase.n_groups > 0 && comb_reads_per_output(p->comb) > 0.8 * (2.0 * p->phase.d_pad)) {
+            comb_set_error(p->comb, "not used: no fewer LDS reads per output than the phase-major kernel");
+            p->comb_state = -1;
+            return nullptr;
+        }
         p->comb_state = -1;
         if (p->comb) {
-            if (comb_load(p->comb)) p->comb_state = 1;
+            if (comb_load(p->comb) && comb_self_test(p)) p->comb_state = 1;
             else if (getenv("PARRM_COMB_VERBOSE")) fprintf(stderr, "parrm: generated filter kernel unavailable: %s\n", comb_error(p->comb));
         }
     }
@@ -650,6 +722,15 @@ int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_inf
         info->phase_row_slots = plan->phase3.m_slots;
         info->phase_residues = 3;
     }
+    return PARRM_OK;
+}
+
+int parrm_filter_plan_generated(const parrm_filter_plan *plan, int *state, int *stride, char *message, size_t message_len) {
+    PARRM_REQUIRE(plan && state, "filter_plan_generated: NULL argument");
+    std::lock_guard<std::mutex> lock(g_comb_mutex);
+    *state = plan->comb_state;
+    if (stride) *stride = plan->comb ? comb_stride(plan->comb) : 0;
+    if (message && message_len) snprintf(message, message_len, "%s", plan->comb ? comb_error(plan->comb) : "");
     return PARRM_OK;
 }
 

@@ -87,7 +87,8 @@ inline int floordiv_round(int64_t u, int64_t q) {  // nearest multiple
 // Geometry for a tap mask and a stride; false when this kernel cannot take the filter.
 bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
-    if (q < 96 || q > 256) return false;
+    // (16 lanes x C residues cover a row; the ring of 64+ rows and the two Delta buffers fit the LDS up to C = 11)
+    if (q < 80 || q > 176) return false;
     g->q = static_cast<int>(q);
     int guard = 0;
     g->a_lo = 1 << 30;
@@ -255,6 +256,9 @@ class Emitter {
                 const int lo = (j - 1) * batch_, hi = std::min(n, lo + batch_);
                 for (int i = lo; i < hi; ++i)
                     if (!compute[i].empty()) o << compute[i];
+                // (and nothing of it sinks below the next batch: the arithmetic would lag further and further behind
+                // the reads and every value read would need a register of its own -- 56 VGPRs in stage B alone)
+                o << "        __builtin_amdgcn_sched_barrier(0);\n";
             }
         }
     }
@@ -309,7 +313,10 @@ class Emitter {
             for (int i = i0; i < i1; ++i) o << "        acc" << i << " = 0.0;\n";
             return;
         }
-        for (int th : local_thetas) o << "        const u32 B1w" << th << " = B1 - (r >= " << th << " ? (u32)RING_BYTES : 0u);\n";
+        // (r goes through an empty asm so that these are NOT loop-invariant to the compiler: hoisted out of the
+        // loop they would hold a dozen registers for the whole kernel)
+        if (!local_thetas.empty()) o << "        int r_now = r;\n        asm volatile(\"\" : \"+v\"(r_now));\n";
+        for (int th : local_thetas) o << "        const u32 B1w" << th << " = B1 - (r_now >= " << th << " ? (u32)RING_BYTES : 0u);\n";
         emit_pipeline(o, "ea", reads, compute);
     }
 
@@ -429,7 +436,7 @@ struct CombArgs {
 __device__ __forceinline__ u32 lds_off(const void *p) { return (u32)(size_t)(const LDS_AS void *)p; }
 
 // one output of a row that touches an end of the recording (divisor = taps inside the recording, parrm.py:862-866)
-__device__ __forceinline__ void emit_edge(double *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
+__device__ __noinline__ void emit_edge(double *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
                                        long long n, double xc, double s) {
     double y;
     if (n >= hw && n + hw < n_total) {
@@ -446,7 +453,7 @@ __device__ __forceinline__ void emit_edge(double *yout, const int *tapcum, long 
 }
 
 // samples n, n + 1 of a row, zero outside [lim_lo, lim_hi) (the ends of the recording / of the addressable window)
-__device__ __forceinline__ u32x4 load_pair_padded(const double *xrow, long long buf_first, long long lim_lo, long long lim_hi, long long n) {
+__device__ __noinline__ u32x4 load_pair_padded(const double *xrow, long long buf_first, long long lim_lo, long long lim_hi, long long n) {
     const double v0 = (n >= lim_lo && n < lim_hi) ? xrow[n - buf_first] : 0.0;
     const double v1 = (n + 1 >= lim_lo && n + 1 < lim_hi) ? xrow[n + 1 - buf_first] : 0.0;
     const u32x2 w0 = __builtin_bit_cast(u32x2, v0), w1 = __builtin_bit_cast(u32x2, v1);
@@ -762,6 +769,16 @@ bool comb_load(CombKernel *k) {
     if (!code_for_source(k->source, &code, &k->error)) return false;
     hipError_t e = hipModuleLoadData(&k->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&k->func, k->module, "parrm_comb_kernel");
+    int scratch = 0;
+    if (e == hipSuccess) e = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->func);
+    if (e == hipSuccess && scratch != 0) {
+        // the row loads are in flight in registers the compiler knows nothing about: a build that spills must not run
+        k->error = "generated kernel uses " + std::to_string(scratch) + " bytes of scratch per lane (register spills)";
+        (void)hipModuleUnload(k->module);
+        k->module = nullptr;
+        k->func = nullptr;
+        return false;
+    }
     if (e != hipSuccess) {
         k->error = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
         if (k->module) (void)hipModuleUnload(k->module);
@@ -773,14 +790,34 @@ bool comb_load(CombKernel *k) {
 }
 
 const char *comb_error(const CombKernel *k) { return k->error.c_str(); }
+void comb_set_error(CombKernel *k, const char *msg) { k->error = msg; }
+int comb_reach(const CombKernel *k) { return (k->geom.a_hi - k->geom.a_lo + 2) * k->geom.q; }
+// LDS reads per real output of stage A (the phase-major kernel's figure is its number of delta taps)
+double comb_reads_per_output(const CombKernel *k) {
+    double reads = 0.0;
+    for (const Unit &u : k->geom.units) reads += k->geom.c + u.width - 1;
+    return reads / k->geom.c * (16.0 * k->geom.c) / static_cast<double>(k->geom.q);
+}
 int comb_stride(const CombKernel *k) { return k->geom.q; }
 
-// The stride the plan's guarded phase search picks for this filter (0: none, or only the wrap form).
+// The stride this kernel works best at for a tap mask: the one with the fewest LDS reads per output among the
+// strides whose geometry it can take (0: none).  Independent of the generic kernels' choice (the phase-major plan
+// may prefer its wrap form or another stride).
 int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw) {
-    parrm_filter_plan tmp;
-    std::vector<int32_t> table;
-    plan_phase(tap, hw, &tmp, &table);
-    return (tmp.phase.n_groups > 0 && !tmp.phase.wrap) ? tmp.phase.q : 0;
+    int64_t best_q = 0;
+    double best = 1e300;
+    for (int64_t q = 80; q <= 176; ++q) {
+        Geom g;
+        if (!make_geom(tap, hw, q, &g)) continue;
+        double reads = 0.0;
+        for (const Unit &u : g.units) reads += g.c + u.width - 1;
+        const double cost = reads / g.c * (16.0 * g.c) / static_cast<double>(q);  // per real output
+        if (cost < best) {
+            best = cost;
+            best_q = q;
+        }
+    }
+    return best_q;
 }
 
 // Launch for float64 in / float64 out, mode 0.  Fills a->stretch_len / a->n_stretch (the repair pass needs them).

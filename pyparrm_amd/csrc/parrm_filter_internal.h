@@ -181,12 +181,16 @@ int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, h
 }  // namespace parrm_filter
 
 namespace parrm_filter {
-// parrm_filter_comb.hip: the per-filter generated kernel (float64 recordings, comb filters with q in [96, 256])
+// parrm_filter_comb.hip: the per-filter generated kernel (float64 recordings, comb filters with q in [80, 176])
 struct CombKernel;
 CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q);
 void comb_destroy(CombKernel *k);
 bool comb_load(CombKernel *k);  // code object from the caches or hipRTC, loaded on the current device
 const char *comb_error(const CombKernel *k);
+void comb_set_error(CombKernel *k, const char *msg);
+int comb_reach(const CombKernel *k);
+double comb_reads_per_output(const CombKernel *k);
+int comb_stride(const CombKernel *k);
 bool comb_accepts(const CombKernel *k, const FilterArgs &a);
 int launch_comb(const CombKernel *k, FilterArgs *a, hipStream_t stream);
 int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw);

@@ -1,0 +1,168 @@
+"""Round-3 GPU parity tests of the per-filter GENERATED filter kernel (pyparrm_amd/csrc/parrm_filter_comb.hip):
+``filter_data`` of float64 recordings (parrm.py:861-869) through a kernel that hipRTC compiles for the one filter.
+Run with ``pytest -m gpu`` on an MI355X.
+
+The oracle is the closed form ``oracle.filter_data_direct``; tolerance max|y - y_ref| <= 1e-10 * max|y_ref|
+(north_star bar: 1e-6).  Every test asserts that the generated kernel really ran (``plan.generated``): a filter
+the generator declines falls back to the generic kernels by design and would make the test vacuous.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import parrm_oracle as orc  # noqa: E402
+from pyparrm_amd import PARRM, _hip  # noqa: E402
+from pyparrm_amd.synth import synth_recording  # noqa: E402
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _hip.require_gpu()
+    torch.cuda.set_device(0)
+
+
+def _default_filter(period, n, omit=0, direction="both"):
+    hw = orc.default_filter_half_width(n, period, omit, period / 50)
+    return orc.generate_filter(period, hw, omit, direction, None), hw
+
+
+def _in_use(plan, may_decline=False):
+    state, stride, msg = plan.generated
+    if may_decline and state == -1 and "scratch" in msg:
+        # the build of this geometry needs more than the 256 registers of two waves per SIMD: refused by design (its
+        # row loads are in flight in registers the compiler does not know about), the generic kernels run instead
+        pytest.skip(f"generated kernel refused for this geometry: {msg}")
+    assert state == 1, f"generated kernel not in use (state {state}, stride {stride}): {msg}"
+    return stride
+
+
+# (sampling, artefact) pairs whose comb stride lies in the generator's range [80, 176]
+GEOMETRIES = [(22000.0, 130.0), (16000.0, 130.0), (20000.0, 185.0), (22000.0, 135.0), (12000.0, 130.0), (18000.0, 130.0)]
+MUST_RUN = {(22000.0, 130.0), (22000.0, 135.0), (20000.0, 185.0)}
+
+
+@pytest.mark.parametrize("fs,fa", GEOMETRIES, ids=lambda v: str(int(v)))
+def test_generated_kernel_matches_the_direct_evaluation(monkeypatch, fs, fa):
+    """Default filters of six sampling geometries (strides 92 ... 169, C = 7 ... 11 outputs per lane), one- and
+    two-sided, centre omitted: the whole recording, both ends included, and a window call."""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    period = fs / fa * (1 + 3e-5)
+    rng = np.random.default_rng(int(fs + fa))
+    for direction, omit, n in (("both", 0, 300_017), ("past", 0, 221_003), ("future", 2, 180_001)):
+        filt, hw = _default_filter(period, n, omit, direction)
+        x = rng.standard_normal((3, n))
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+        stride = _in_use(plan, may_decline=(fs, fa) not in MUST_RUN)
+        assert abs(stride - period) < 1.0 or abs(stride - round(period)) <= 1, (stride, period)
+        ref = orc.filter_data_direct(x, filt)
+        assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), (fs, fa, direction, omit)
+        o0, olen = n // 3 + 1, n // 4
+        b0, b1 = max(o0 - hw, 0), min(o0 + olen + hw, n)
+        part = plan.apply_window(torch.from_numpy(np.ascontiguousarray(x[:, b0:b1])).cuda(), b0, o0, olen, n).cpu().numpy()
+        assert np.abs(part - ref[:, o0:o0 + olen]).max() <= TOL * np.abs(ref).max(), (fs, fa, direction, "window")
+
+
+def test_generated_kernel_explicit_half_widths_and_short_recordings(monkeypatch):
+    """create_filter's other parameters change the tap geometry the kernel is generated for: shorter and longer
+    half-widths (fewer / more rows of reach: other ring sizes), a wide omitted centre, a recording barely longer
+    than the filter (every row touches an end)."""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    period = 22000 / 130 * (1 + 3e-5)
+    rng = np.random.default_rng(5)
+    for hw, omit, n in ((900, 0, 120_001), (2372, 40, 90_000), (2900, 0, 150_000), (2372, 0, 5_200)):
+        filt = orc.generate_filter(period, hw, omit, "both", None)
+        x = rng.standard_normal((2, n))
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+        state, _, msg = plan.generated
+        if state != 1:  # (a geometry outside the generator's range runs the generic kernels: still must be right)
+            assert "self-test" not in msg, msg
+        ref = orc.filter_data_direct(x, filt)
+        assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), (hw, omit, n, state)
+
+
+def test_generated_kernel_is_the_default_for_large_float64_launches_only(monkeypatch):
+    """Policy: a launch of >= 2^25 samples takes the generated kernel (a possible compile is worth it), a small
+    one keeps the generic kernel, float32 recordings keep theirs, PARRM_COMB=0 turns the generated kernel off."""
+    monkeypatch.delenv("PARRM_COMB", raising=False)
+    filt, _ = _default_filter(22000 / 130 * (1 + 3e-5), 10_000_000)
+    small = _hip.FilterPlan(filt)
+    small.apply(torch.zeros((2, 100_000), dtype=torch.float64, device="cuda"))
+    assert small.generated[0] == 0
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((32, 1_200_000), dtype=torch.float64, device="cuda", generator=g)
+    big = _hip.FilterPlan(filt)
+    y = big.apply(x)
+    _in_use(big)
+    f32 = _hip.FilterPlan(filt)
+    f32.apply(x.to(torch.float32))
+    assert f32.generated[0] == 0
+    monkeypatch.setenv("PARRM_COMB", "0")
+    off = _hip.FilterPlan(filt)
+    y_generic = off.apply(x)
+    assert off.generated[0] == 0
+    ref_scale = y_generic.abs().max().item()
+    assert (y - y_generic).abs().max().item() <= TOL * ref_scale
+
+
+def test_generated_kernel_channel_blocks_and_repeat_launches_are_bit_identical(monkeypatch):
+    """configs[3]: a channel block planned as the whole recording returns the whole recording's bits; so does
+    launching twice (the kernel keeps row loads in flight in registers across iterations -- a run-to-run
+    difference would be a race)."""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    rng = np.random.default_rng(17)
+    filt = orc.generate_filter(169.2359, 2372)
+    plan = _hip.FilterPlan(filt)
+    x = torch.from_numpy(rng.standard_normal((48, 1_500_000))).cuda()
+    whole = plan.apply(x)
+    _in_use(plan)
+    for _ in range(3):
+        assert torch.equal(plan.apply(x), whole)
+    for rows in (6, 16):
+        parts = [plan.apply(x[lo:lo + rows].contiguous(), total_chans=48) for lo in range(0, 48, rows)]
+        assert torch.equal(torch.cat(parts), whole), rows
+
+
+def test_generated_kernel_nonfinite_samples_only_zero_the_outputs_they_reach(monkeypatch):
+    """parrm.py:869 through the generated kernel + the repair pass: NaN / +-Inf samples zero exactly the outputs
+    whose taps reach them (the oracle's places), everything else keeps its value."""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    period = 22000 / 130 * (1 + 3e-5)
+    for direction in ("both", "past", "future"):
+        n = 400_003
+        filt, hw = _default_filter(period, n, 0, direction)
+        x = synth_recording(3, n, 22000, 130, seed=11)
+        x[0, 123_456] = np.nan
+        x[1, 5] = np.inf
+        x[1, n - 3] = -np.inf
+        x[2, 200_000:200_040] = np.nan
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+        _in_use(plan)
+        ref = orc.filter_data_direct(x, filt)
+        assert np.isfinite(y).all()
+        assert np.array_equal(y == 0, ref == 0), direction
+        assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), direction
+
+
+def test_facade_filter_data_uses_the_generated_kernel_at_config_scale():
+    """The reference's own calling sequence (find_period -> create_filter -> filter_data, parrm.py:148, :689, :835)
+    on a device-resident recording large enough for the default policy: sampled-oracle check of the output."""
+    fs, fa = 22000.0, 130.0
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((40, 1_000_000), dtype=torch.float64, device="cuda", generator=g)
+    p = PARRM(x, fs, fa, verbose=False)
+    p._period = np.float64(fs / fa * (1 + 3e-5))
+    p.create_filter()
+    y = p.filter_data()
+    y = y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y)
+    xs = x[[0, 17, 39]].cpu().numpy()
+    ref = orc.filter_data_direct(xs, p.filter)
+    assert np.abs(y[[0, 17, 39]] - ref).max() <= TOL * np.abs(ref).max()
