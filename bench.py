@@ -114,13 +114,42 @@ def spawn_ranks(args) -> int:
     return status
 
 
-def run_cpu_baseline():
-    """The oracle on the host cores, as a child process that never sees the GPU."""
-    res = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline"], cwd=ROOT, capture_output=True, text=True)
+def run_cpu_baseline(save_path=None):
+    """The oracle on the host cores, as a child process that never sees the GPU.  ``save_path``: the 8 channels
+    of its configs[2] subsample are written there, and the GPU recording takes them as its first 8 channels, so
+    that both legs work on the same samples."""
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline"] + (["--save-cfg3", save_path] if save_path else [])
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
     if res.returncode != 0:
         return {"error": res.stderr[-400:]}
     out = json.loads(res.stdout.strip().splitlines()[-1])
     return {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "period", "configs", "wall_s")}
+
+
+def default_taps(period, n_samples):
+    """Tap offsets of the default filter for a period (parrm.py:788-833), host arithmetic only."""
+    from pyparrm_amd import PARRM
+
+    p = PARRM(np.zeros((1, n_samples)), FS, F_ART, verbose=False)
+    p._period = np.float64(period)
+    p.create_filter()
+    f = p.filter
+    return np.flatnonzero((f != 0) & (np.arange(f.size) != f.size // 2))
+
+
+def launch_ms(fn, reps=5):
+    """Mean duration of `fn` (one kernel launch sequence on torch's current stream) by HIP events, one warm-up."""
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def run_cfg5(args, rank, local_rank, world):
@@ -221,8 +250,11 @@ def main():
         return run_cfg5(args, rank, local_rank, world)
 
     cpu = None
+    shared_path = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = run_cpu_baseline()  # before this process initialises the GPU
+        if args.chans >= 8 and args.samples == 10_000_000:
+            shared_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"parrm_bench_cfg3_{os.getpid()}.npy")
+        cpu = run_cpu_baseline(shared_path)  # before this process initialises the GPU
 
     import torch
 
@@ -251,20 +283,31 @@ def main():
         exchange = TorchExchange(dist, via_host=args.exchange == "host")
     else:
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
+    shared_rows = 0
+    if shared_path and os.path.exists(shared_path):
+        # the channels the CPU baseline just worked on become the first channels of the GPU's recording
+        head = np.load(shared_path, mmap_mode="r")
+        if head.shape[1] == n_samples and head.shape[0] <= x.shape[0]:
+            shared_rows = head.shape[0]
+            x[:shared_rows] = torch.from_numpy(np.array(head)).to(x.device)
+        del head
+        os.unlink(shared_path)
     torch.cuda.synchronize()
     assumed = assumed_periods_1e4()
 
-    timings = {"find": [], "filter_total": [], "filter_kernel": []}
+    timings = {"find": [], "filter_total": [], "filter_kernel": [], "grids": []}
     state = {}
 
     def step(record: bool):
         p = ShardedPARRM(x, FS, F_ART, exchange, verbose=False) if strong else PARRM(x, FS, F_ART, verbose=False)
         t0 = time.perf_counter()
+        _hip.FIT_GRID_EVENTS = []
         if args.filter_only and "period" in state:
             p._period = state["period"]
         else:
             p.find_period(assumed_periods=assumed, random_seed=44)
         t1 = time.perf_counter()
+        grids, _hip.FIT_GRID_EVENTS = _hip.FIT_GRID_EVENTS, None
         p.create_filter()
         # the filter launch is bracketed by HIP events on the stream it is launched on
         # (pyparrm_amd._hip.FilterPlan.apply records them right around the C-ABI call)
@@ -274,9 +317,12 @@ def main():
         t2 = time.perf_counter()
         (ev0, ev1), = _hip.FILTER_LAUNCH_EVENTS
         _hip.FILTER_LAUNCH_EVENTS = None
-        state.update(period=p.period, filt=p.filter, info=p._plan.info)
+        state.update(period=p.period, filt=p.filter, info=p._plan.info, generated=p._plan.generated)
         del y, p  # the output goes back to torch's caching allocator for the next step
         if record:
+            # candidate grids: bracketed duration and algorithmic flops 2 n K (C + K) per candidate
+            timings["grids"].append([(e0.elapsed_time(e1), 2.0 * n * (2 * bw + 1) * (c + 2 * bw + 1) * npd, npd, 2 * bw + 1)
+                                     for e0, e1, n, c, npd, bw in grids])
             timings["find"].append(t1 - t0)
             timings["filter_total"].append(t2 - t1)
             timings["filter_kernel"].append(ev0.elapsed_time(ev1) * 1e-3)
@@ -339,7 +385,8 @@ def main():
                            "row_groups": int(info.phase_groups), "rows_per_thread": int(info.phase_rows)},
             },
             "roofline": {
-                "kernel": {1: "filter_gather_kernel", 2: "filter_stride_kernel", 3: "filter_phase_kernel", 4: "filter_phase_kernel (segmented plan)"}[int(info.kernel)] + "<double,double>",
+                "kernel": ("parrm_comb_kernel (generated for this filter by hipRTC, stride %d)" % state["generated"][1]) if state["generated"][0] == 1 else
+                          {1: "filter_gather_kernel", 2: "filter_stride_kernel", 3: "filter_phase_kernel", 4: "filter_phase_kernel (segmented plan)"}[int(info.kernel)] + "<double,double>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -356,7 +403,50 @@ def main():
             },
             "period": float(state["period"]),
         }
+        # ---- second roofline: the candidate grids of find_period (matrix-core bound, 78.6 TFLOP/s FP64)
+        if timings["grids"] and timings["grids"][0]:
+            per_step_ms = float(np.mean([sum(g[0] for g in gs) for gs in timings["grids"]]))
+            flops = float(np.mean([sum(g[1] for g in gs) for gs in timings["grids"]]))
+            out["roofline_find_period"] = {
+                "kernel": "fit_accum_mfma_kernel (bracket = one grid call: design matrices, Gram blocks, reduction, solves)",
+                "bound": "fp64-mfma", "flops": flops, "ms_per_step": per_step_ms,
+                "achieved": flops / per_step_ms / 1e9, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / per_step_ms / 1e9 / 78.6,
+                "grids": [{"candidates": g[2], "K": g[3], "ms": g[0]} for g in timings["grids"][-1]],
+                "note": "algorithmic flops 2 n K (C + K) per candidate (SURVEY.md 8d); Nelder-Mead batches are not in the bracket",
+            }
+        # ---- other configurations and dtypes, untimed region: a few launches each
+        if world == 1 and not args.filter_only:
+            extra = []
+            plan = _hip.FilterPlan(state["filt"])
+
+            def roof(config, kernel, ms, bytes_per_sample, n_c, n_s):
+                gbs = bytes_per_sample * n_c * n_s / ms / 1e6
+                extra.append({"config": config, "kernel": kernel, "ms": ms, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+
+            def kernel_name(pl):
+                return "parrm_comb_kernel (generated)" if pl.generated[0] == 1 else "filter_phase_kernel"
+
+            x2 = x[:64, :1_000_000].contiguous()
+            y2 = torch.empty_like(x2)
+            roof("configs[1]: 64 ch x 1 M float64, filter_data only", kernel_name(plan), launch_ms(lambda: plan.apply(x2, out=y2)), 16, 64, 1_000_000)
+            del x2, y2
+            p32 = _hip.FilterPlan(state["filt"])
+            x32 = x.to(torch.float32)
+            y32 = torch.empty_like(x32)
+            roof(f"{rows} ch x {n_samples} float32 -> float32 (configs[4]'s dtype, resident)", "filter_phase_kernel<float,float> (packed)",
+                 launch_ms(lambda: p32.apply(x32, out=y32, out_dtype=torch.float32), 3), 8, rows, n_samples)
+            del y32
+            y64 = torch.empty((rows, n_samples), dtype=torch.float64, device=x.device)
+            roof(f"{rows} ch x {n_samples} float32 -> float64 (the reference's dtype rule)", "filter_phase_kernel<float,double>",
+                 launch_ms(lambda: p32.apply(x32, out=y64), 3), 12, rows, n_samples)
+            del x32, y64
+            out["extra"] = {"rooflines": extra}
         if cpu is not None:
+            if shared_rows and "period" in cpu:
+                cpu["shared_channels"] = shared_rows
+                cpu["taps_equal"] = bool(np.array_equal(default_taps(cpu["period"], n_samples), default_taps(state["period"], n_samples)))
+                cpu["note"] = (f"the {shared_rows} channels of the configs[2] subsample are channels 0-{shared_rows - 1} of the GPU's "
+                               "recording; taps_equal compares the default filters of the two periods (CPU: those 8 channels, GPU: all 256)")
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -114,8 +114,10 @@ class _FilterRow:
         return orc.filter_data_fft(self.x[chan:chan + 1], self.filt)
 
 
-def run_config(name, n_chans, n_samples, mapper, find=True, assumed=None, seed=6000):
+def run_config(name, n_chans, n_samples, mapper, find=True, assumed=None, seed=6000, save=None):
     x = _recording(n_chans, n_samples, seed, mapper)
+    if save:  # bench.py loads these rows as the first channels of the recording the GPU works on
+        np.save(save, x)
     out = {"config": name, "n_chans": n_chans, "n_samples": n_samples}
     t_find = 0.0
     if find:
@@ -141,6 +143,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=0)
     ap.add_argument("--quick", action="store_true", help="tiny sizes (tests)")
+    ap.add_argument("--save-cfg3", default=None, help="write the configs[2] subsample's channels to this .npy file")
     args = ap.parse_args()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     procs = args.procs or max(1, min(16, avail))
@@ -153,7 +156,7 @@ def main():
                       1_000_000 // scale, mapper, find=False, seed=6200)
     cfg3 = run_config("configs[2] subsample: 8 of 256 channels x 10 M, find_period over the 26-estimate grid "
                       "+ filter_data", 8 // (4 if args.quick else 1), 10_000_000 // scale, mapper,
-                      assumed=assumed_periods_1e4(), seed=6300)
+                      assumed=assumed_periods_1e4(), seed=6300, save=args.save_cfg3)
     result = {
         "value": cfg3["msamples_per_s"],
         "unit": "Msamples/s",

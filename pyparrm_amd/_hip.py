@@ -101,6 +101,9 @@ _lock = threading.Lock()
 # bench.py sets this to a list: every filter launch then appends a (start, stop) pair of HIP
 # events recorded on the launch's own stream, so the kernel's duration can be read after a sync
 FILTER_LAUNCH_EVENTS = None
+# same for the candidate grids of find_period (calls of >= 64 candidates): entries are
+# (start, stop, n_idx, n_chans, n_candidates, bandwidth)
+FIT_GRID_EVENTS = None
 
 
 def library_path() -> str:
@@ -650,6 +653,10 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
         buf = ws.get(nbytes, y.device)
         out = np.empty(n_per, dtype=np.float64)
         with _on_device(torch, y.device):
+            events = None
+            if FIT_GRID_EVENTS is not None and n_per >= 64:
+                events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                events[0].record()
             check(
                 L.parrm_fit_errors_host(
                     y.data_ptr(), y.stride(0), idx.data_ptr(), n_idx, n_chans,
@@ -658,12 +665,19 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
                 ),
                 "parrm_fit_errors_host",
             )
+            if events is not None:
+                events[1].record()
+                FIT_GRID_EVENTS.append((events[0], events[1], int(n_idx), int(n_chans), int(n_per), int(bandwidth)))
         return out
     h_per, h_err, d_per, d_err = ws.staging(n_per, y.device)
     h_per[:n_per] = torch.from_numpy(periods)
     with torch.cuda.device(y.device):
         stream = _stream_ptr(torch)
         d_per[:n_per].copy_(h_per[:n_per], non_blocking=True)
+        events = None
+        if FIT_GRID_EVENTS is not None and n_per >= 64:
+            events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            events[0].record()
         for lo in range(0, n_per, batch):
             cnt = min(batch, n_per - lo)
             nbytes = ws.nbytes(n_idx, n_chans, cnt, bandwidth, grid)
@@ -676,6 +690,9 @@ def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, work
                 ),
                 "parrm_fit_errors_slice",
             )
+        if events is not None:
+            events[1].record()
+            FIT_GRID_EVENTS.append((events[0], events[1], int(n_idx), int(n_chans), int(n_per), int(bandwidth)))
         h_err[:n_per].copy_(d_err[:n_per], non_blocking=True)
         torch.cuda.current_stream().synchronize()
     return h_err[:n_per].numpy().copy()

@@ -542,7 +542,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
             for (int i = 0; i < g.nld; ++i) o << "    u32x4 pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
 
         // the two stage-A wave sets split each lane's C outputs; set 0 holds the stage-B waves and takes fewer
-        int c_split = (g.c * 4 + 5) / 11;  // 4 of 11
+        int c_split = (g.c * 3 + 5) / 11;  // 3 of 11 (measured: 2 and 3 tie, 4 is 1 % slower, 5 is 2.5 % slower)
         if (const char *e = getenv("PARRM_COMB_SPLIT")) c_split = atoi(e);
         c_split = std::min(g.c - 1, std::max(1, c_split));
         std::ostringstream bodies;
@@ -828,9 +828,13 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     // a_hi - a_lo + 2 NR rows and one tap-by-tap evaluation (~ 5 rows' worth).  Long recordings: ~1 M samples.
     const int64_t q = g.q;
     const int64_t prologue_rows = g.a_hi - g.a_lo + 2 * kNR + 8;
-    int64_t target = int64_t{1} << 20;
+    // Equal stretches: a recording is cut into round(length / ~0.9 M) stretches of the same number of rows (the
+    // last one a little shorter), not into 1 M stretches plus a remainder -- 10 M samples in 1 M stretches left a
+    // tenth round with half-empty workgroups (8.45 -> 8.25 ms).
+    int64_t target = 917504;
     if (const char *env = getenv("PARRM_COMB_STRETCH")) target = std::max<int64_t>(atoll(env), q * kNR);
-    int64_t rows = std::max<int64_t>(kNR, (target / q) / kNR * kNR);
+    const int64_t n_cut = std::max<int64_t>(1, (a.out_len + target / 2) / target);
+    int64_t rows = std::max<int64_t>(kNR, (((a.out_len + n_cut - 1) / n_cut + q - 1) / q + kNR - 1) / kNR * kNR);
     auto blocks_for = [&](int64_t r) { return a.plan_chans * ((a.out_len + r * q - 1) / (r * q)); };
     if (blocks_for(rows) < 2048 && !getenv("PARRM_COMB_STRETCH")) {
         const int64_t resident = 256;
