@@ -190,6 +190,7 @@ class Emitter {
         // profiling ablations (results wrong by construction): 1 no tap reads, 2 no output stores, 4 no row requests,
         // 8 no second barrier, 16 no stage B at all.  Part of the source text, so each has its own code object.
         if (const char *e = getenv("PARRM_COMB_DEBUG")) debug_ = atoi(e);
+        if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0;
     }
 
     // (base register, immediate) of element `col` of ring row m - a for lane row r, at ring phase km
@@ -222,10 +223,11 @@ class Emitter {
     //   reads[i]        : where value e<prefix><i> comes from
     //   compute[i]      : statements that may run once read i (and every earlier one) is back
     void emit_pipeline(std::ostringstream &o, const std::string &prefix, const std::vector<Read> &reads,
-                       const std::vector<std::string> &compute, int batch = 0) const {
+                       const std::vector<std::string> &compute, int batch = 0, bool wide = false) const {
         const int batch_ = batch ? batch : this->batch_;
         const int n = static_cast<int>(reads.size());
-        o << "        double";
+        const char *op = wide ? "ds_read_b128" : "ds_read_b64";
+        o << (wide ? "        d2" : "        double");
         for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << prefix << i;
         o << ";\n";
         const int nb = (n + batch_ - 1) / batch_;
@@ -239,7 +241,7 @@ class Emitter {
                 o << "        asm volatile(";
                 for (int i = lo; i < hi; ++i) {
                     const int bi = static_cast<int>(std::find(bases.begin(), bases.end(), reads[i].base) - bases.begin());
-                    o << "\"ds_read_b64 %" << (i - lo) << ", %" << (hi - lo + bi) << " offset:" << reads[i].imm << "\\n\\t\"\n                     ";
+                    o << "\"" << op << " %" << (i - lo) << ", %" << (hi - lo + bi) << " offset:" << reads[i].imm << "\\n\\t\"\n                     ";
                 }
                 if (j > 0) o << "\"s_waitcnt lgkmcnt(" << (hi - lo) << ")\"";
                 else o << "\"\"";
@@ -348,6 +350,41 @@ class Emitter {
         emit_pipeline(o, "eb", reads, compute, 6);  // three rows per batch
     }
 
+    // The same with TWO residues per lane (2j, 2j + 1): 16-byte LDS reads and 16-byte output stores on
+    // ceil(Q / 2) lanes; an odd Q leaves the last lane one residue, stored by an 8-byte store of its own.
+    void emit_stage_b_wide(std::ostringstream &o, int km) const {
+        std::vector<Read> reads;
+        std::vector<std::string> compute;
+        for (int r = 0; r < kNR; ++r) {
+            const int slot = (kNR * km + g_.ofs + r) % g_.ms;
+            Read x;
+            if (slot < g_.hs) {
+                x.base = "xb0";
+                x.imm = slot * g_.pb;
+            } else {
+                x.base = "xb1";
+                x.imm = (slot - g_.hs) * g_.pb;
+            }
+            reads.push_back(x);
+            compute.push_back("");
+            reads.push_back({"dbk", r * g_.dpb});
+            std::ostringstream s;
+            const int ix = 2 * r;
+            s << "        { d2 yv; yv.x = __builtin_fma(-S, inv_taps, eb" << ix << ".x); yv.y = __builtin_fma(-S1, inv_taps, eb" << ix << ".y);\n";
+            if (debug_ & 2) {
+                s << "          asm volatile(\"\" :: \"v\"(yv));\n";
+            } else if (g_.q & 1) {
+                s << "          if (rho2 + 1 < Q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n"
+                  << "          else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv.x), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n";
+            } else {
+                s << "          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n";
+            }
+            s << "          S += eb" << ix + 1 << ".x; S1 += eb" << ix + 1 << ".y; }\n";
+            compute.push_back(s.str());
+        }
+        emit_pipeline(o, "eb", reads, compute, 6, true);
+    }
+
     // Request the NR rows of iteration `kk` (an expression) into register set `set`.  The loads are inline asm and
     // the wait before the set is copied into the ring is a COUNTED vmcnt written by hand (emit_write_iter): with
     // compiler-visible loads hipcc drained the queue (vmcnt(0)) once per ring period, i.e. gave up the whole
@@ -408,13 +445,13 @@ class Emitter {
         const int P = g.period;
         o << "// generated by parrm_filter_comb.hip -- q " << g.q << ", C " << g.c << ", " << g.units.size() << " delta units\n";
         o << "typedef unsigned int u32;\ntypedef unsigned int u32x2 __attribute__((ext_vector_type(2)));\n"
-          << "typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));\n";
+          << "typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));\ntypedef double d2 __attribute__((ext_vector_type(2)));\n";
         o << "#define LDS_AS __attribute__((address_space(3)))\n";
         o << "#define Q " << g.q << "\n#define CC " << g.c << "\n#define NR " << kNR << "\n#define MS " << g.ms << "\n#define HB " << g.hb
           << "\n#define NCOL " << g.ncol << "\n#define PB " << g.pb << "\n#define DPB " << g.dpb << "\n#define AHI " << g.a_hi
           << "\n#define ALO (" << g.a_lo << ")\n#define OFS " << g.ofs << "\n#define RING_BYTES " << g.ring_bytes << "\n#define DBYTES " << g.d_bytes
           << "\n#define LDS_TOTAL " << g.lds_total << "\n#define HSTEP " << g.hs * g.pb << "\n#define CH16 " << g.ch16
-          << "\n#define PERIOD " << g.period << "\n#define ATHREADS " << kAThreads << "\n#define BTHREADS " << g.b_threads << "\n#define NTHREADS " << g.threads << "\n#define N_RUNS " << g.runs.size() << "\n";
+          << "\n#define PERIOD " << g.period << "\n#define ATHREADS " << kAThreads << "\n#define BTHREADS " << (wide_b_ ? ((g.q + 1) / 2 + 63) / 64 * 64 : g.b_threads) << "\n#define RPL " << (wide_b_ ? 2 : 1) << "\n#define NTHREADS " << g.threads << "\n#define N_RUNS " << g.runs.size() << "\n";
         o << "__device__ const int RUN_A[N_RUNS] = {";
         for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].a;
         o << "};\n__device__ const int RUN_BLO[N_RUNS] = {";
@@ -497,7 +534,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     // every wave computes tap sums (stage A); the first ceil(Q / 64) waves also turn the tap sums of the PREVIOUS
     // iteration into outputs (stage B) before they start on this one
     const bool wave_has_b = __builtin_amdgcn_readfirstlane(tid) < BTHREADS;
-    const int rho = tid;  // stage-B lane: residue
+    const int rho = tid * RPL;  // stage-B lane: its first residue (RPL residues per lane)
 
     // prologue: rows [-AHI, -ALO + NR) -> slots OFS - AHI .. (everything iteration 0 reads), 16-byte chunks
 #pragma unroll 1
@@ -508,12 +545,15 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     }
     __syncthreads();
     // running tap sum of row 0, evaluated tap by tap (thread = residue)
-    double S = 0.0;
+    double S = 0.0, S1 = 0.0;
     if (rho < Q) {
 #pragma unroll 1
         for (int rr = 0; rr < N_RUNS; ++rr) {
             const double *rowp = reinterpret_cast<const double *>(smem + (OFS - RUN_A[rr]) * PB) + (HB + rho);
-            for (int b = RUN_BLO[rr]; b <= RUN_BHI[rr]; ++b) S += rowp[-b];
+            for (int b = RUN_BLO[rr]; b <= RUN_BHI[rr]; ++b) {
+                S += rowp[-b];
+                if (RPL == 2) S1 += rowp[1 - b];
+            }
         }
     }
     // stage-A lane: wave set hs takes its half of the delta units for row r of the iteration, residues [l*CC, l*CC + CC)
@@ -554,8 +594,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
                    << "        const long long nrow = s0 + (long long)kk * (NR * Q);\n"
                    << "        const bool fast = (kk + 1) * NR * (long long)Q + s0 <= s_end && nrow >= a.hw && nrow + NR * Q - 1 + a.hw < a.n_total;\n"
                    << "        if (fast) {\n          if (rho < Q" << ((debug_ & 16) ? " && false" : "") << ") {\n"
-                   << "          const u32 yoff = ystart + (u32)kk * (u32)(NR * Q * 8);\n          const u32 dbk = db + (u32)(kk & 1) * DBYTES;\n";
-            emit_stage_b(bodies, kmb);
+                   << "          const u32 yoff = ystart + (u32)kk * (u32)(NR * Q * 8);\n          const u32 dbk = db + (u32)(kk & 1) * DBYTES;\n"
+                   << "          const int rho2 = rho;\n          (void)rho2;\n";
+            if (wide_b_) emit_stage_b_wide(bodies, kmb);
+            else emit_stage_b(bodies, kmb);
             bodies << "          }\n        } else {\n          stage_b_generic(kk);\n        }\n        }\n";
             // 1. request the rows of iteration k + P
             emit_load_iter(bodies, km, "k + " + std::to_string(P));
@@ -592,12 +634,16 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
 #pragma unroll 1
             for (int rr = 0; rr < NR; ++rr) {
                 const int sl = (NR * kk + OFS + rr) % MS;
-                const double xr = *reinterpret_cast<const double *>(smem + sl * PB + (HB + rho) * 8);
-                const double dr = *reinterpret_cast<const double *>(smem + RING_BYTES + (kk & 1) * DBYTES + rr * DPB + rho * 8);
+                const double *xp = reinterpret_cast<const double *>(smem + sl * PB + (HB + rho) * 8);
+                const double *dp = reinterpret_cast<const double *>(smem + RING_BYTES + (kk & 1) * DBYTES + rr * DPB + rho * 8);
                 const int m = kk * NR + rr;
                 const long long n = s0 + (long long)m * Q + rho;
-                if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xr, S);
-                S += dr;
+                if (m < rows_total && n < s_end) emit_edge(a.y + ch * a.ldy + (n - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n, xp[0], S);
+                S += dp[0];
+                if (RPL == 2 && rho + 1 < Q) {
+                    if (m < rows_total && n + 1 < s_end) emit_edge(a.y + ch * a.ldy + (n + 1 - a.out_first), a.tapcum, a.hw, a.n_total, inv_taps, n + 1, xp[1], S1);
+                    S1 += dp[1];
+                }
             }
         }
     };
@@ -614,6 +660,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     const Geom &g_;
     int batch_;
     int debug_ = 0;
+    bool wide_b_ = false;  // stage B: two residues per lane, 16-byte reads and stores
 };
 
 // ---------------------------------------------------------------------------------------------- code objects
