@@ -127,10 +127,11 @@ int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int
                              int64_t ldx, int64_t ldy, void *stream);
 
 /* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host uses buffers that are
- * already page-locked in place (the fast path); a buffer that is not is locked by the call itself only
- * when it is >= 64 MiB (~20 ms per GiB per call -- more than moving the data), and goes through staging
- * buffers of the call's own otherwise (a lock covers whole pages and HIP does not count references, so a
- * small buffer's first and last page may belong to someone else's allocation as well).  A caller that
+ * already page-locked in place (the fast path) -- the WHOLE range must lie inside one registration -- and
+ * stages every other buffer through page-locked buffers of the call's own: it never locks caller memory
+ * itself (PARRM_HOST_LOCK=1 restores that for buffers >= 64 MiB that are allocations of their own; a lock
+ * covers whole pages, HIP does not count references, and a range locked, unlocked and locked again has
+ * faulted under DMA on ROCm 7.2 -- profiles/r03_host_register_fault.txt).  A caller that
  * filters the same recording repeatedly -- the reference's parameter explorer re-filters on every widget
  * event (_utils/_plotting.py:568-584) -- locks it once with parrm_host_pin; the buffer must then stay
  * allocated until parrm_host_unpin, and nothing else may lock or unlock a range that shares a page with

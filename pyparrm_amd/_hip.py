@@ -11,6 +11,7 @@ import atexit
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -190,11 +191,24 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_SHUT_DOWN = False
+_LIVE_PLANS: set = set()  # weak references to every FilterPlan alive
+
+
 def _shutdown() -> None:
-    _PLAN_CACHE.clear()  # plans free their device tables while the runtime is up
+    global _SHUT_DOWN
+    # every live plan frees its device tables NOW, while the runtime is up: a plan still held by a PARRM object
+    # or an OnlineFilter would otherwise reach hipFree from __del__ during interpreter finalisation
+    for ref in list(_LIVE_PLANS):
+        plan = ref()
+        if plan is not None:
+            plan._release()
+    _LIVE_PLANS.clear()
+    _PLAN_CACHE.clear()
     _INDEX_STAGING.clear()
     if _lib is not None:
         _lib.parrm_hip_shutdown()
+    _SHUT_DOWN = True
 
 
 def check(rc: int, what: str = "") -> None:
@@ -286,6 +300,7 @@ class FilterPlan:
                 lib().parrm_filter_plan_create(f.ctypes.data_as(C.c_void_p), f.shape[0], C.byref(self._h)),
                 "parrm_filter_plan_create",
             )
+        _LIVE_PLANS.add(weakref.ref(self, _LIVE_PLANS.discard))
 
     def _refuse_copy(self, *_args):
         raise TypeError("a FilterPlan owns device memory and cannot be copied or pickled; build one "
@@ -300,10 +315,13 @@ class FilterPlan:
                 "build a plan for that device"
             )
 
-    def __del__(self):
+    def _release(self):
         h, self._h = getattr(self, "_h", None), None
-        if h is not None and h.value and _lib is not None:
+        if h is not None and h.value and _lib is not None and not _SHUT_DOWN:
             _lib.parrm_filter_plan_destroy(h)
+
+    def __del__(self):
+        self._release()
 
     @property
     def info(self) -> PlanInfo:
@@ -413,6 +431,7 @@ class FilterPlan:
 
 _PLAN_CACHE: dict = {}
 _PLAN_CACHE_SIZE = 16
+_PLAN_CACHE_LOCK = threading.Lock()
 
 
 def precompile_filter_kernel(filt: np.ndarray, out_dir: str | None = None, stride: int = 0) -> str:
@@ -436,14 +455,19 @@ def shared_filter_plan(filt: np.ndarray, device: int) -> FilterPlan:
     a period.  Plans with a forced kernel variant (tests) are never shared: this returns AUTO plans only."""
     f = np.ascontiguousarray(filt, dtype=np.float64)
     key = (int(device), f.shape[0], hash(f.tobytes()))
-    hit = _PLAN_CACHE.get(key)
-    if hit is not None and np.array_equal(hit[0], f):
-        _PLAN_CACHE[key] = _PLAN_CACHE.pop(key)  # most recently used last
-        return hit[1]
-    plan = FilterPlan(f, device=device)
-    _PLAN_CACHE[key] = (f.copy(), plan)
-    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
-        _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    with _PLAN_CACHE_LOCK:
+        hit = _PLAN_CACHE.get(key)
+        if hit is not None and np.array_equal(hit[0], f):
+            _PLAN_CACHE[key] = _PLAN_CACHE.pop(key)  # most recently used last
+            return hit[1]
+    plan = FilterPlan(f, device=device)  # (outside the lock: a stride search, a hipMalloc and an upload)
+    with _PLAN_CACHE_LOCK:
+        hit = _PLAN_CACHE.get(key)
+        if hit is not None and np.array_equal(hit[0], f):  # another thread built it meanwhile
+            return hit[1]
+        _PLAN_CACHE[key] = (f.copy(), plan)
+        while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
     return plan
 
 
@@ -484,6 +508,8 @@ def unpin_host(array: np.ndarray) -> None:
 
 _NO_LEAN_CALLS = bool(os.environ.get("PARRM_NO_LEAN_CALLS"))  # A/B knob: the generic wrapper for every call
 _INDEX_STAGING: dict = {}
+_STAGING_LOCK = threading.Lock()  # the staging vector is filled and copied from under this lock (two
+#                                   threads searching on one device overwrote each other's indices mid-copy)
 
 
 def upload_indices(indices: np.ndarray, device):
@@ -496,12 +522,13 @@ def upload_indices(indices: np.ndarray, device):
     if n and int(idx[-1]) - int(idx[0]) + 1 == n and (n < 3 or bool(np.all(idx[1:] - idx[:-1] == 1))):
         return torch.arange(int(idx[0]), int(idx[0]) + n, dtype=torch.int64, device=device)
     key = torch.device(device).index
-    staging = _INDEX_STAGING.get(key)
-    if staging is None or staging.shape[0] < n:
-        staging = torch.empty(max(n, 32768), dtype=torch.int64).pin_memory()
-        _INDEX_STAGING[key] = staging
-    staging[:n] = torch.from_numpy(idx)
-    return staging[:n].to(device)  # blocking: the staging vector is free again on return
+    with _STAGING_LOCK:
+        staging = _INDEX_STAGING.get(key)
+        if staging is None or staging.shape[0] < n:
+            staging = torch.empty(max(n, 32768), dtype=torch.int64).pin_memory()
+            _INDEX_STAGING[key] = staging
+        staging[:n] = torch.from_numpy(idx)
+        return staging[:n].to(device)  # blocking: the staging vector is free again when the lock is released
 
 
 def absdiff_mean(x):

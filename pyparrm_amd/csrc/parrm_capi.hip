@@ -82,17 +82,45 @@ static bool is_pinned_host(const void *p) {
     return attr.type == hipMemoryTypeHost;
 }
 
+// Is the WHOLE range [p, p + bytes) page-locked, inside one registration?  (is_pinned_host looks at the first
+// byte only: a registration that is shorter than the buffer -- the caller pinned a smaller array that has since
+// been freed and reallocated larger, or pinned a neighbour that shares the first page -- would let the copy
+// engines run past the locked range.)
+static bool is_pinned_range(const void *p, size_t bytes) {
+    if (bytes == 0 || !is_pinned_host(p)) return false;
+    void *start = nullptr;
+    size_t size = 0;
+    const hipDeviceptr_t dp = const_cast<void *>(p);
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, dp) == hipSuccess &&
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, dp) == hipSuccess && start && size) {
+        return static_cast<const char *>(p) + bytes <= static_cast<const char *>(start) + size;
+    }
+    (void)hipGetLastError();  // attribute not available: the last byte must at least be page-locked too
+    return is_pinned_host(static_cast<const char *>(p) + bytes - 1);
+}
+
+// Optional trace of every lock / unlock this library performs (PARRM_HOST_TRACE=1, stderr): round 2 met a GPU page
+// fault at a heap address and could only argue about its cause afterwards -- the next one can be matched to a range.
+static void trace_lock(const char *what, const void *p, size_t bytes, int rc) {
+    static const bool on = getenv("PARRM_HOST_TRACE") != nullptr;
+    if (on) fprintf(stderr, "parrm host: %s [%p, %p) %zu bytes -> %d\n", what, p, static_cast<const char *>(p) + bytes, bytes, rc);
+}
+
 int parrm_host_pin(void *h_ptr, size_t bytes) {
     PARRM_REQUIRE(h_ptr && bytes > 0, "host_pin: NULL or empty buffer");
-    if (is_pinned_host(h_ptr)) return PARRM_OK;
-    PARRM_HIP_CHECK(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    if (is_pinned_range(h_ptr, bytes)) return PARRM_OK;
+    const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);
+    trace_lock("pin", h_ptr, bytes, static_cast<int>(e));
+    PARRM_HIP_CHECK(e);
     return PARRM_OK;
 }
 
 int parrm_host_unpin(void *h_ptr) {
     PARRM_REQUIRE(h_ptr, "host_unpin: NULL buffer");
     if (!is_pinned_host(h_ptr)) return PARRM_OK;
-    PARRM_HIP_CHECK(hipHostUnregister(h_ptr));
+    const hipError_t e = hipHostUnregister(h_ptr);
+    trace_lock("unpin", h_ptr, 0, static_cast<int>(e));
+    PARRM_HIP_CHECK(e);
     return PARRM_OK;
 }
 
@@ -103,9 +131,10 @@ int parrm_host_unpin(void *h_ptr) {
 // How the caller's host buffers reach the copy engines, per buffer:
 //   * already page-locked (hipHostMalloc, hipHostRegister, parrm_host_pin, a torch pinned tensor): used
 //     in place -- the fast path (80+ GB/s both ways);
-//   * not locked and >= 64 MiB: locked in place for the duration of the call (hipHostRegister; ~20 ms per
-//     GiB) and released on every exit path;
-//   * not locked and smaller (or the lock was refused): the chunks go through page-locked staging
+//   * not locked: the chunks go through page-locked staging buffers the call owns (below).  (With
+//     PARRM_HOST_LOCK=1 a buffer of >= 64 MiB that is an allocation of its own is locked in place for the
+//     duration of the call instead -- rounds 1-2's default, retired: see usable_in_place.)
+//   * staged: the chunks go through page-locked staging
 //     buffers the call owns, filled and drained by the calling thread.  A registration covers whole
 //     pages and HIP does not count references (a second hipHostRegister of a range succeeds and ONE
 //     hipHostUnregister drops the mapping -- scripts/exp_host_register.py), so locking a small buffer
@@ -138,9 +167,26 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     constexpr size_t kLockInPlaceMin = size_t{64} << 20;
     bool locked_x = false, locked_y = false;  // locked by this call: released below
     auto usable_in_place = [&](const void *p, size_t bytes, bool *locked_here) {
-        if (is_pinned_host(p)) return true;
-        if (bytes >= kLockInPlaceMin && !getenv("PARRM_HOST_NO_LOCK")) {
-            if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
+        if (is_pinned_range(p, bytes)) return true;  // first AND last byte inside one registration
+        if (is_pinned_host(p)) return false;         // partly locked by someone else: neither trusted nor re-locked
+        // Locked in place only when the buffer is an allocation of its own: >= 64 MiB (glibc never serves that from
+        // the heap) AND it starts within a malloc header of a page boundary.  A row-block VIEW of a larger array
+        // (sharding.shard_recording; np.ascontiguousarray does not copy it) starts anywhere inside its parent's
+        // mapping: its first and last page belong to the neighbouring blocks as well, two threads filtering two
+        // blocks would lock and unlock each other's edge pages (a registration covers whole pages, HIP keeps no
+        // reference count) -- such a buffer is staged, or its caller pins the parent array once (parrm_host_pin).
+        //
+        // Since round 3 the call does not lock caller memory at all unless PARRM_HOST_LOCK=1: a range that had been
+        // registered, unregistered and registered AGAIN (the second call on the same array) took a GPU page fault
+        // inside the range the second hipHostRegister had reported as locked (profiles/r03_host_register_fault.txt:
+        // the trace of every lock next to the faulting address) -- the same signature as round 2's unexplained
+        // fault.  Unlocked buffers are staged through page-locked buffers the call owns; callers who need the
+        // in-place rate allocate page-locked memory (hipHostMalloc, a torch pinned tensor) once.
+        const bool own_mapping = (reinterpret_cast<uintptr_t>(p) & 4095u) <= 128u;
+        if (bytes >= kLockInPlaceMin && own_mapping && getenv("PARRM_HOST_LOCK")) {
+            const hipError_t er = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+            trace_lock("lock for the call", p, bytes, static_cast<int>(er));
+            if (er == hipSuccess) {
                 *locked_here = true;
                 return true;
             }
@@ -151,8 +197,8 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
     const bool direct_x = usable_in_place(h_x, x_bytes, &locked_x);
     const bool direct_y = usable_in_place(h_y, y_bytes, &locked_y);
     auto unpin = [&]() {
-        if (locked_x) (void)hipHostUnregister(const_cast<void *>(h_x));
-        if (locked_y) (void)hipHostUnregister(h_y);
+        if (locked_x) trace_lock("unlock", h_x, x_bytes, static_cast<int>(hipHostUnregister(const_cast<void *>(h_x))));
+        if (locked_y) trace_lock("unlock", h_y, y_bytes, static_cast<int>(hipHostUnregister(h_y)));
     };
     if (chunk_samples <= 0) {
         // ~256 MiB of input per chunk when both buffers are used in place (PARRM_HOST_CHUNK_MB), 4 MiB when a side is

@@ -370,7 +370,10 @@ class PARRM:
         if self._streams_from_host():
             # gather the two samples of every difference on the host and let the device kernel do the
             # same arithmetic on the compact array: x'[c, 2j] = x[c, idx_j], x'[c, 2j+1] = x[c, idx_j + 1]
-            pairs = np.empty((self._n_chans, 2 * indices.shape[0]), dtype=self._data.dtype)
+            # (float32 and float64 keep their type -- the reference differences a float32 recording in float32,
+            # parrm.py:272-280 -- anything else is promoted, as on the resident path and in the statistics pass)
+            pair_dtype = self._data.dtype if self._data.dtype in (np.float32, np.float64) else np.float64
+            pairs = np.empty((self._n_chans, 2 * indices.shape[0]), dtype=pair_dtype)
             pairs[:, 0::2] = self._data[:, indices]
             pairs[:, 1::2] = self._data[:, indices + 1]
             x = torch.from_numpy(pairs).cuda()

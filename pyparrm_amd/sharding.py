@@ -17,9 +17,17 @@ What shards (reference shape of the split in brackets):
 * the Nelder-Mead refinements (parrm.py:510-517, :545-550) are a chain of dependent evaluations:
   every rank runs them redundantly on its replica (no exchange, identical results).
 
-The exchange goes through an :class:`Exchange` object: ``TorchExchange`` rides on the process
-group the launcher created (``all_gather``; RCCL over xGMI when the group's backend is nccl, host
-memory when it is gloo), ``ThreadExchange`` runs N ranks as threads of one process (tests).
+The exchange goes through an :class:`Exchange` object:
+
+* ``DeviceExchange`` -- N ranks as N host threads of ONE process, one device each, pieces moved by peer copies:
+  what :class:`MultiDevicePARRM` (the single-process, NumPy-in / NumPy-out facade over all the GPUs of a node;
+  SURVEY.md section 7 step 6: "one host thread + stream per device, no collectives") is built on;
+* ``ShmExchange`` -- one process per GPU (a launcher such as ``torch.distributed.run``), pieces staged through
+  POSIX shared memory: no RCCL anywhere in the data path (BASELINE.json's north_star), ``torch.distributed`` only
+  provides the barrier.  ``bench.py --gpus N`` uses it by default;
+* ``TorchExchange`` -- the same processes, pieces by ``all_gather`` on the launcher's process group (RCCL over xGMI
+  when its backend is nccl, host memory when it is gloo): the fallback when shared memory is not available;
+* ``ThreadExchange`` -- N thread-ranks on one device (tests).
 
 ``timed_steps`` is the benchmark's timing protocol (barrier + MAX over ranks).
 """
@@ -136,6 +144,121 @@ class ThreadExchange(Exchange):
         return parts
 
 
+class DeviceExchange(ThreadExchange):
+    """N ranks as N host threads of one process, rank r bound to ``devices[r]`` (the same device may appear more
+    than once: rehearsals on one GPU).  ``all_gather`` hands every rank the other ranks' tensors as copies on ITS
+    device -- peer-to-peer copies over xGMI where the devices can reach each other, staged by the runtime otherwise;
+    no collective library is involved."""
+
+    def __init__(self, rank, world_size, slots, barrier, device):
+        super().__init__(rank, world_size, slots, barrier)
+        self.device = device
+
+    @classmethod
+    def group(cls, devices):
+        devices = list(devices)
+        slots, barrier = [None] * len(devices), threading.Barrier(len(devices))
+        return [cls(rank, len(devices), slots, barrier, dev) for rank, dev in enumerate(devices)]
+
+    def all_gather(self, tensor):
+        import torch
+
+        # the producer's work on its stream must be complete before another thread's stream reads the tensor
+        if tensor.is_cuda:
+            torch.cuda.current_stream(tensor.device).synchronize()
+        self._slots[self.rank] = tensor
+        self._barrier.wait()
+        mine = torch.device("cuda", self.device)
+        parts = [t if (not t.is_cuda or t.device == mine) else t.to(mine) for t in self._slots]
+        if tensor.is_cuda:
+            torch.cuda.current_stream(mine).synchronize()  # the copies have read their sources
+        self._barrier.wait()  # nobody overwrites a slot before every rank has read it
+        return parts
+
+
+class ShmExchange(Exchange):
+    """One process per GPU, pieces staged through POSIX shared memory (``/dev/shm``): every rank owns one segment,
+    writes its piece there (device -> host copy straight into the mapping), and reads the other ranks' segments
+    (host -> device) between two barriers of a gloo group.  Nothing of RCCL is in the data path; the 51 MB stage
+    matrix of a 256-channel recording crosses PCIe twice (~2 ms) instead of xGMI once.
+
+    ``dist``: an initialised ``torch.distributed``; a gloo group for the barriers is created next to the default
+    group when that one is nccl."""
+
+    def __init__(self, dist, tag: str | None = None):
+        import os
+
+        self._dist = dist
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        self._group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+        self._tag = tag or f"parrm{os.environ.get('MASTER_PORT', '0')}"
+        self._mine = None          # (SharedMemory, capacity)
+        self._theirs = {}          # rank -> (SharedMemory, capacity)
+        self._seq = 0
+
+    def _barrier(self):
+        self._dist.barrier(group=self._group)
+
+    def _segment(self, nbytes: int):
+        from multiprocessing import shared_memory
+
+        if self._mine is None or self._mine[1] < nbytes:
+            if self._mine is not None:
+                self._mine[0].close()
+                self._mine[0].unlink()
+            cap = max(nbytes, 1 << 20)
+            name = f"{self._tag}_r{self.rank}_g{self._seq}"
+            self._mine = (shared_memory.SharedMemory(name=name, create=True, size=cap), cap, name)
+        return self._mine
+
+    def all_gather(self, tensor):
+        import torch
+        from multiprocessing import shared_memory
+
+        src = tensor.contiguous()
+        nbytes = src.numel() * src.element_size()
+        self._seq += 1
+        seg = self._segment(nbytes)
+        host = torch.frombuffer(seg[0].buf, dtype=src.dtype, count=src.numel()).view(src.shape)
+        host.copy_(src)  # device -> shared memory (blocking)
+        # every rank tells the others which segment holds its piece of this round (names change when one grows)
+        names = [None] * self.world_size
+        self._dist.all_gather_object(names, seg[2], group=self._group)  # doubles as the "everybody has written" barrier
+        parts = []
+        for rank, name in enumerate(names):
+            if rank == self.rank:
+                parts.append(src)
+                continue
+            cur = self._theirs.get(rank)
+            if cur is None or cur[1] != name:
+                if cur is not None:
+                    cur[0].close()
+                cur = (shared_memory.SharedMemory(name=name), name)
+                self._theirs[rank] = cur
+            view = torch.frombuffer(cur[0].buf, dtype=src.dtype, count=src.numel()).view(src.shape)
+            parts.append(view.to(src.device) if src.is_cuda else view.clone())
+        self._barrier()  # nobody rewrites its segment before every rank has read it
+        return parts
+
+    def close(self):
+        for seg in self._theirs.values():
+            seg[0].close()
+        self._theirs = {}
+        if self._mine is not None:
+            self._mine[0].close()
+            try:
+                self._mine[0].unlink()
+            except FileNotFoundError:
+                pass
+            self._mine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------------------ sharded facade
 class ShardedPARRM(PARRM):
     """``PARRM`` for ONE recording whose channels are spread over the ranks of an ``Exchange``.
@@ -222,6 +345,223 @@ class ShardedPARRM(PARRM):
         ex = self._exchange
         return (f"ShardedPARRM object | rank {ex.rank} of {ex.world_size} | Data: ({self._n_chans} channels x "
                 f"{self._n_samples} times) | Period: {self._period:.4f}")
+
+
+class MultiDevicePARRM:
+    """The ``PARRM`` surface for ONE recording spread over several GPUs of THIS process: NumPy array in, NumPy
+    array out, no launcher, no process group, no collective library.
+
+        p = MultiDevicePARRM(data, sampling_freq, artefact_freq)            # all visible devices
+        p.find_period(); p.create_filter(); clean = p.filter_data()
+
+    One host thread per device drives a :class:`ShardedPARRM` on that device's channel block (SURVEY.md section 7
+    step 6); the threads meet in :class:`DeviceExchange` (peer copies) twice per search stage.  ``period`` and the
+    filtered recording are bit-identical to a single-device ``PARRM`` on the same array (the candidate grids are
+    planned as whole grids, the time axis is cut as for the whole recording).
+
+    ``devices``: device indices, one rank each (default: every visible device; an index may repeat -- rehearsals
+    of the N-rank path on one GPU).  A recording with fewer channels than devices uses as many devices as channels."""
+
+    def __init__(self, data, sampling_freq, artefact_freq, devices=None, verbose=True) -> None:
+        torch = _hip.require_gpu()
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("`devices` must name at least one GPU.")
+        probe = PARRM(data, sampling_freq, artefact_freq, verbose)  # the reference's checks, in its order
+        devices = devices[: max(1, min(len(devices), probe._n_chans))]
+        self._devices = devices
+        self._data = data
+        self._verbose = verbose
+        exchanges = DeviceExchange.group(devices)
+        blocks = [shard_recording(data, r, len(devices)) for r in range(len(devices))]
+        self._ranks = [ShardedPARRM(block, sampling_freq, artefact_freq, ex, verbose and r == 0)
+                       for r, (block, ex) in enumerate(zip(blocks, exchanges))]
+        self._filtered_data = None
+
+    @classmethod
+    def from_blocks(cls, blocks, sampling_freq, artefact_freq, verbose=True):
+        """The same for a recording that is ALREADY resident: ``blocks`` are CUDA tensors, the consecutive channel
+        blocks of one recording, one per device (block r on ``blocks[r].device``).  ``filter_data()`` then returns the
+        list of filtered blocks, each on its device -- nothing crosses PCIe."""
+        self = cls.__new__(cls)
+        blocks = list(blocks)
+        if not blocks or any(not getattr(b, "is_cuda", False) or b.ndim != 2 for b in blocks):
+            raise TypeError("`blocks` must be a non-empty sequence of 2D CUDA tensors.")
+        self._devices = [int(b.device.index) for b in blocks]
+        self._data = blocks
+        self._verbose = verbose
+        exchanges = DeviceExchange.group(self._devices)
+        self._ranks = [ShardedPARRM(b, sampling_freq, artefact_freq, ex, verbose and r == 0)
+                       for r, (b, ex) in enumerate(zip(blocks, exchanges))]
+        self._filtered_data = None
+        return self
+
+    @property
+    def devices(self):
+        return list(self._devices)
+
+    def _on_every_rank(self, call):
+        """``call(rank_object)`` on every rank, each in a thread of its own with its device current; the first
+        exception (in rank order) is re-raised here after every thread has finished or aborted."""
+        import torch
+
+        results, errors = [None] * len(self._ranks), [None] * len(self._ranks)
+        barrier = self._ranks[0]._exchange._barrier
+
+        def work(r):
+            try:
+                torch.cuda.set_device(self._devices[r])
+                results[r] = call(self._ranks[r])
+            except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread
+                errors[r] = exc
+                barrier.abort()  # ranks waiting in an exchange must not wait for this one forever
+
+        if len(self._ranks) == 1:
+            work(0)
+        else:
+            threads = [threading.Thread(target=work, args=(r,), name=f"parrm-rank{r}") for r in range(len(self._ranks))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+        if real or any(errors):
+            barrier.reset()
+            raise (real or [e for e in errors if e is not None])[0]
+        return results
+
+    def find_period(self, search_samples=None, assumed_periods=None, outlier_boundary=3.0, random_seed=None,
+                    n_jobs=1) -> None:
+        """parrm.py:148-194 on the whole recording; every rank ends with the same period."""
+        self._filtered_data = None
+        self._on_every_rank(lambda p: p.find_period(search_samples, assumed_periods, outlier_boundary, random_seed, n_jobs))
+
+    def create_filter(self, filter_half_width=None, omit_n_samples=0, filter_direction="both", period_half_width=None) -> None:
+        """parrm.py:689-737 (host arithmetic, identical on every rank)."""
+        self._filtered_data = None
+        for p in self._ranks:
+            p.create_filter(filter_half_width, omit_n_samples, filter_direction, period_half_width)
+
+    def filter_data(self, data=None) -> np.ndarray:
+        """parrm.py:835-875: every device filters its channel block; returns the whole filtered recording."""
+        if data is None and isinstance(self._data, list):  # resident blocks: results stay on their devices
+            self._filtered_data = self._on_every_rank(lambda p: p.filter_data())
+            return self._filtered_data
+        if data is None:
+            blocks = self._on_every_rank(lambda p: np.asarray(p.filter_data()))
+        else:
+            probe = self._ranks[0]._check_sort_filter_data_inputs(data)  # the reference's checks
+            n = len(self._ranks)
+            parts = [shard_recording(probe, r, n) for r in range(n)]
+            total = int(probe.shape[0])
+
+            def one(p):
+                r = p._exchange.rank
+                if parts[r].shape[0] == 0:
+                    return np.empty((0, probe.shape[1]))
+                x = p._device_recording(parts[r])
+                try:
+                    y = p._plan_for(x.device).apply(x, total_chans=total)
+                    return _hip.to_host_numpy(y)
+                finally:
+                    p._end_call()
+
+            if self._ranks[0]._filter is None:
+                raise ValueError("The filter has not yet been created. The `create_filter` method must be called first.")
+            blocks = self._on_every_rank(one)
+        self._filtered_data = np.concatenate(blocks, axis=0)
+        return self._filtered_data
+
+    # the reference's read-only properties (parrm.py:888-936)
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def period(self):
+        return self._ranks[0].period
+
+    @property
+    def filter(self):
+        return self._ranks[0].filter
+
+    @property
+    def filtered_data(self):
+        if self._filtered_data is None:
+            raise AttributeError("No data has been filtered, so the filtered data cannot be returned.")
+        return self._filtered_data
+
+    @property
+    def settings(self):
+        return self._ranks[0].settings
+
+    def __repr__(self) -> str:
+        n_chans = sum(p._n_chans for p in self._ranks)
+        return f"MultiDevicePARRM object | devices {self._devices} | Data: ({n_chans} channels x {self._ranks[0]._n_samples} times)"
+
+
+def filter_host_sharded(filt: np.ndarray, x: np.ndarray, out: np.ndarray | None = None, devices=None,
+                        out_dtype=None, chunk_samples: int = 0) -> np.ndarray:
+    """BASELINE configs[4] as a package call: a HOST recording ``x[C, N]`` (float32 or float64; page-locked or not)
+    filtered with the filter array ``filt`` through every device of this process -- contiguous channel blocks,
+    one host thread per device, each block streamed through its device in time chunks with a half-width halo
+    (``parrm_filter_host``), no exchange.  Returns the filtered recording (``out`` if given).
+
+    Arrays in page-locked memory (``torch.empty(..., pin_memory=True).numpy()``, ``hipHostMalloc``) are used in
+    place -- the 80 GB/s path; anything else is staged through page-locked buffers of the library's own.  The
+    library does not lock caller memory itself: a range registered, unregistered and registered again faulted
+    under DMA (``profiles/r03_host_register_fault.txt``); ``PARRM_HOST_PIN_PARENTS=1`` restores the round-2
+    behaviour of locking large parent arrays once per call."""
+    import torch
+
+    _hip.require_gpu()
+    if x.ndim != 2:
+        raise ValueError("`x` must be a 2D array.")
+    if devices is None:
+        devices = list(range(torch.cuda.device_count()))
+    devices = [int(d) for d in devices][: max(1, min(len(devices), x.shape[0]))]
+    out_dtype = np.dtype(out_dtype or (np.float32 if x.dtype == np.float32 else np.float64))
+    if out is None:
+        out = np.empty(x.shape, dtype=out_dtype)
+    if out.shape != x.shape or out.dtype != out_dtype or not out.flags.c_contiguous or not x.flags.c_contiguous:
+        raise ValueError("`x` and `out` must be C-contiguous arrays of one shape (`out` of the output dtype).")
+    pinned = []
+    import os
+
+    for arr in (x, out) if os.environ.get("PARRM_HOST_PIN_PARENTS") else ():
+        if arr.nbytes >= (64 << 20):
+            try:
+                _hip.pin_host(arr)
+                pinned.append(arr)
+            except _hip.HipLibraryError:
+                pass  # lock limit: the blocks are staged instead
+    errors = [None] * len(devices)
+
+    def work(r):
+        try:
+            lo, hi = channel_shard(x.shape[0], r, len(devices))
+            if hi > lo:
+                torch.cuda.set_device(devices[r])
+                plan = _hip.FilterPlan(filt, device=devices[r])
+                plan.apply_host(x[lo:hi], out_dtype=out_dtype.type, chunk_samples=chunk_samples, out=out[lo:hi])
+        except BaseException as exc:  # noqa: BLE001
+            errors[r] = exc
+
+    try:
+        threads = [threading.Thread(target=work, args=(r,), name=f"parrm-host{r}") for r in range(len(devices))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        for arr in pinned:
+            _hip.unpin_host(arr)
+    for e in errors:
+        if e is not None:
+            raise e
+    return out
 
 
 def timed_steps(step, n_steps: int, n_warmup: int, dist=None, sync=None) -> float:

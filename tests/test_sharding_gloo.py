@@ -171,3 +171,84 @@ def test_sharded_parrm_two_rank_gloo(tmp_path):
     out = tmp_path / "ok.txt"
     mp.spawn(_sharded_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def _shm_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from oracle import parrm_oracle as orc
+    from pyparrm_amd import sharding as sh
+    from pyparrm_amd.synth import synth_recording_exact
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = sh.ShmExchange(dist, tag=f"parrmtest{port}")
+    try:
+        # the exchange itself: pieces of every rank, in rank order, through growing segments
+        for rows in (3, 50_000, 7):
+            t = torch.arange(rows * 4, dtype=torch.float64).reshape(rows, 4) + 1000.0 * rank
+            parts = ex.all_gather(t)
+            assert len(parts) == world
+            for r, part in enumerate(parts):
+                assert torch.equal(part, torch.arange(rows * 4, dtype=torch.float64).reshape(rows, 4) + 1000.0 * r)
+        # the product's sharded search on top of it
+        _install_oracle_device(torch, orc)
+        fs, fa = 1000.0, 130.0
+        x = synth_recording_exact(3, 2600, fs / fa * (1 + 4e-4), seed=77)
+        p = sh.ShardedPARRM(sh.shard_recording(x, rank, world), fs, fa, ex, verbose=False)
+        p.find_period(random_seed=5)
+        assert float(p.period) == float(orc.find_period(x, fs, fa, random_seed=5))
+        p.create_filter()
+        lo, hi = sh.channel_shard(3, rank, world)
+        assert np.array_equal(p.filter_data(), orc.filter_data_direct(x, p.filter)[lo:hi])
+        if rank == 0:
+            open(out_path, "w").write("ok")
+    finally:
+        ex.close()
+        dist.destroy_process_group()
+
+
+def test_sharded_parrm_over_shared_memory_exchange(tmp_path):
+    """``ShmExchange``: one process per rank, the pieces staged through POSIX shared memory (no collective
+    library in the data path; ``torch.distributed`` -- gloo here -- only synchronises)."""
+    out = tmp_path / "ok.txt"
+    mp.spawn(_shm_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
+
+
+def _multi_device_in_subprocess(_rank, out_path):
+    sys.path.insert(0, ROOT)
+    from oracle import parrm_oracle as orc
+    from pyparrm_amd import sharding as sh
+    from pyparrm_amd.synth import synth_recording_exact
+
+    _install_oracle_device(torch, orc)
+    # no GPU here: the thread-ranks' device binding and peer copies become no-ops on CPU tensors
+    torch.cuda.set_device = lambda d: None
+    sh.DeviceExchange.all_gather = sh.ThreadExchange.all_gather
+    fs, fa = 1000.0, 130.0
+    x = synth_recording_exact(5, 2600, fs / fa * (1 + 4e-4), seed=78)
+    p = sh.MultiDevicePARRM(x, fs, fa, devices=[0, 0, 0], verbose=False)
+    p.find_period(random_seed=5)
+    assert float(p.period) == float(orc.find_period(x, fs, fa, random_seed=5))
+    with pytest.raises(ValueError):
+        sh.MultiDevicePARRM(x, fs, fa, devices=[0, 0], verbose=False).filter_data()  # the reference's call-order rule
+    p.create_filter()
+    y = p.filter_data()
+    assert y.shape == x.shape and np.array_equal(y, orc.filter_data_direct(x, p.filter))
+    other = x[:4, :1500] * 2.0
+    assert np.array_equal(p.filter_data(other), orc.filter_data_direct(other, p.filter))
+    assert isinstance(p.settings, dict) and p.filtered_data is not None
+    # an error on one rank comes back to the caller and leaves the object usable
+    with pytest.raises(ValueError):
+        p.find_period(outlier_boundary=-1.0)
+    p.find_period(random_seed=5)
+    open(out_path, "w").write("ok")
+
+
+def test_multi_device_facade_threads_with_oracle_device(tmp_path):
+    """``MultiDevicePARRM`` (one process, one host thread per device): the reference's surface, NumPy in and out,
+    three thread-ranks over blocks of 2 + 2 + 1 channels; the oracle stands in for the device (in a child process:
+    the stand-ins are monkey-patches of the binding)."""
+    out = tmp_path / "ok.txt"
+    mp.spawn(_multi_device_in_subprocess, args=(str(out),), nprocs=1, join=True)
+    assert out.read_text() == "ok"
