@@ -69,9 +69,13 @@ def parse():
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 (default): the headline, resident f64 find_period + filter_data; cfg5: BASELINE "
                          "configs[4], float32 recording streamed from page-locked host memory, filter_data only")
-    ap.add_argument("--exchange", choices=["device", "host"], default="device",
-                    help="strong mode: the two all-gathers per stage on the process group's device collective "
-                         "(RCCL over xGMI with nccl) or staged through host memory over a gloo group (no RCCL at all)")
+    ap.add_argument("--exchange", choices=["shm", "device", "host"], default="shm",
+                    help="strong mode under a launcher: the two exchanges per stage staged through POSIX shared memory "
+                         "(default: no RCCL in the data path; falls back to `device` if shared memory cannot be set up), "
+                         "on the process group's device collective (RCCL over xGMI with nccl), or through a gloo group")
+    ap.add_argument("--spawn", action="store_true",
+                    help="no launcher and --gpus N > 1: start N rank processes (default: ONE process, one host thread "
+                         "per device -- sharding.MultiDevicePARRM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-only", action="store_true", help="time filter_data alone (config 2 style)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -236,11 +240,76 @@ def run_cfg5(args, rank, local_rank, world):
         dist.destroy_process_group()
 
 
+def run_threads(args):
+    """``python bench.py --gpus N`` without a launcher: ONE process, one host thread per device, the recording's
+    channel blocks resident on their devices, peer copies for the two small exchanges per stage
+    (``sharding.MultiDevicePARRM``).  Same workload and the same JSON line as the launcher path."""
+    import torch
+
+    from pyparrm_amd import PARRM, _hip
+    from pyparrm_amd.sharding import MultiDevicePARRM, channel_shard
+    from pyparrm_amd.synth import synth_recording_device
+
+    _hip.require_gpu()
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.single_device:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
+    devices = [0] * args.gpus if args.single_device else list(range(args.gpus))
+    n_chans, n_samples = args.chans, args.samples
+    blocks = []
+    for r, dev in enumerate(devices):
+        lo, hi = channel_shard(n_chans, r, args.gpus)
+        with torch.cuda.device(dev):
+            blocks.append(synth_recording_device(n_chans, n_samples, FS, F_ART, seed=0, chan_range=(lo, hi), device=f"cuda:{dev}"))
+    assumed = assumed_periods_1e4()
+
+    def sync():
+        for dev in set(devices):
+            torch.cuda.synchronize(dev)
+
+    def step():
+        p = MultiDevicePARRM.from_blocks(blocks, FS, F_ART, verbose=False)
+        p.find_period(assumed_periods=assumed, random_seed=44)
+        p.create_filter()
+        y = p.filter_data()
+        sync()
+        period = p.period
+        del y, p
+        return period
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        period = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    out = {
+        "metric": "Msamples/s through find_period+filter_data",
+        "value": n_chans * n_samples * args.steps / elapsed / 1e6,
+        "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": (f"{n_chans} ch x {n_samples} samples float64, 22 kHz / 130 Hz synthetic DBS; find_period over "
+                         f"{len(PARRM._get_possible_periods(assumed, 1))} stage-1 candidates (26 assumed periods) + stages 2-3 + polish, "
+                         "create_filter defaults, filter_data"),
+            "parallelism": (f"one recording, channel blocks on {args.gpus} devices of ONE process (one host thread per device, "
+                            "peer copies for the two exchanges per stage, no process group, no RCCL), Nelder-Mead replicated"),
+        },
+        "period": float(period),
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(args))
+        if args.spawn or args.workload != "cfg3" or args.mode != "strong":
+            raise SystemExit(spawn_ranks(args))
+        return run_threads(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     rank = int(os.environ.get("RANK", "0"))
@@ -280,7 +349,18 @@ def main():
     if strong:
         lo, hi = channel_shard(n_chans, rank, world)
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=0, chan_range=(lo, hi))
-        exchange = TorchExchange(dist, via_host=args.exchange == "host")
+        exchange_name = args.exchange
+        if args.exchange == "shm":
+            try:
+                from pyparrm_amd.sharding import ShmExchange
+
+                exchange = ShmExchange(dist)
+            except Exception as exc:  # e.g. /dev/shm not writable: the device collective is the fallback
+                print(f"bench.py: shared-memory exchange unavailable ({exc}); using the device collective", file=sys.stderr)
+                exchange_name = "device"
+                exchange = TorchExchange(dist)
+        else:
+            exchange = TorchExchange(dist, via_host=args.exchange == "host")
     else:
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
     shared_rows = 0
@@ -352,7 +432,7 @@ def main():
         elif strong:
             parallelism = (f"one recording, channel blocks of {rows} rows on {world} GPUs; filter_data and the statistics "
                            "pass without exchange, candidate grids in per-rank slices over a replicated stage matrix "
-                           f"(2 all-gathers per stage, {'staged through host memory (gloo)' if args.exchange == 'host' or args.backend != 'nccl' else 'RCCL over xGMI'}), "
+                           f"(2 exchanges per stage, {'staged through POSIX shared memory, no RCCL in the data path' if exchange_name == 'shm' else 'staged through host memory (gloo)' if exchange_name == 'host' or args.backend != 'nccl' else 'RCCL all_gather over xGMI'}), "
                            "Nelder-Mead replicated")
         else:
             parallelism = f"{world} independent recordings, one per GPU, no exchange"

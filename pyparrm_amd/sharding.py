@@ -234,6 +234,13 @@ class ShmExchange(Exchange):
                 if cur is not None:
                     cur[0].close()
                 cur = (shared_memory.SharedMemory(name=name), name)
+                try:  # (Python < 3.13 also registers ATTACHED segments with the resource tracker, which then
+                    #  unlinks -- or warns about -- segments this process never owned)
+                    from multiprocessing import resource_tracker
+
+                    resource_tracker.unregister(cur[0]._name, "shared_memory")
+                except Exception:
+                    pass
                 self._theirs[rank] = cur
             view = torch.frombuffer(cur[0].buf, dtype=src.dtype, count=src.numel()).view(src.shape)
             parts.append(view.to(src.device) if src.is_cuda else view.clone())
