@@ -508,7 +508,8 @@ def main():
 
             x2 = x[:64, :1_000_000].contiguous()
             y2 = torch.empty_like(x2)
-            roof("configs[1]: 64 ch x 1 M float64, filter_data only", kernel_name(plan), launch_ms(lambda: plan.apply(x2, out=y2)), 16, 64, 1_000_000)
+            ms2 = launch_ms(lambda: plan.apply(x2, out=y2))
+            roof("configs[1]: 64 ch x 1 M float64, filter_data only", kernel_name(plan), ms2, 16, 64, 1_000_000)
             del x2, y2
             p32 = _hip.FilterPlan(state["filt"])
             x32 = x.to(torch.float32)

@@ -12,7 +12,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$ROOT/scripts/profile_filter.py" --kernel phase --reps 1 > "$OUT/g$i.log" 2>&1 || echo "group $i failed"
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$ROOT/scripts/profile_filter.py" --kernel ${KERNEL:-auto} --reps 1 > "$OUT/g$i.log" 2>&1 || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
@@ -24,7 +24,7 @@ for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(out + "/summary.txt", "w") as fh:
     for k, d in tot.items():
-        if "filter" not in k: continue
+        if "filter" not in k and "comb" not in k: continue
         fh.write(k + "\n")
         for c, v in sorted(d.items()): fh.write(f"  {c} {v:.6g}\n")
 print(open(out + "/summary.txt").read())
