@@ -188,7 +188,8 @@ class Emitter {
    public:
     explicit Emitter(const Geom &g, int batch) : g_(g), batch_(batch) {
         // profiling ablations (results wrong by construction): 1 no tap reads, 2 no output stores, 4 no row requests,
-        // 8 no second barrier, 16 no stage B at all.  Part of the source text, so each has its own code object.
+        // 8 no second barrier, 16 no stage B at all, 32 no wait before the ring copy.  Part of the source text, so each has
+        // its own code object.
         if (const char *e = getenv("PARRM_COMB_DEBUG")) debug_ = atoi(e);
         if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0;
     }
@@ -430,8 +431,9 @@ class Emitter {
         // retired, whatever the loads are doing -- stores retire ahead of older loads often enough to corrupt a few
         // stretches per launch (measured).  "At most 9 outstanding" can only be the 9 youngest loads, because loads
         // retire in order among themselves; it merely makes those waves wait for stores issued a whole stage A ago.
-        o << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
-          << "        else asm volatile(\"s_waitcnt vmcnt(" << std::min(63, younger_loads) << ")\" ::: \"memory\");\n";
+        if (!(debug_ & 32))
+            o << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
+              << "        else asm volatile(\"s_waitcnt vmcnt(" << std::min(63, younger_loads) << ")\" ::: \"memory\");\n";
         for (int i = 0; i < g_.nld; ++i) {
             o << "        ";
             if (partial && i == g_.nld - 1) o << "if (lvalid) ";
@@ -459,6 +461,24 @@ class Emitter {
         o << "};\n__device__ const int RUN_BHI[N_RUNS] = {";
         for (size_t i = 0; i < g.runs.size(); ++i) o << (i ? "," : "") << g.runs[i].b_hi;
         o << "};\n";
+        // running tap sum of row 0, tap by tap (thread = residue): generated straight-line with the ring offsets as
+        // constants and four partial sums, so that the reads are in flight together (a loop over the run table
+        // was a chain of ~200 dependent LDS round trips, ~7 us per stretch)
+        std::ostringstream sd;
+        sd << "    double S = 0.0, S1 = 0.0;\n    if (rho < Q) {\n        const double *sdp = reinterpret_cast<const double *>(smem) + (HB + rho);\n"
+           << "        double sa0 = 0.0, sa1 = 0.0, sa2 = 0.0, sa3 = 0.0, sb0 = 0.0, sb1 = 0.0, sb2 = 0.0, sb3 = 0.0;\n";
+        {
+            int n = 0;
+            for (const Run &r : g.runs)
+                for (int b = r.b_lo; b <= r.b_hi; ++b, ++n) {
+                    const int el = (g.ofs - r.a) * g.pitch - b;
+                    sd << "        sa" << (n & 3) << " += sdp[" << el << "];";
+                    if (wide_b_) sd << " sb" << (n & 3) << " += sdp[" << el + 1 << "];";
+                    sd << "\n";
+                }
+        }
+        sd << "        S = (sa0 + sa1) + (sa2 + sa3);\n        S1 = (sb0 + sb1) + (sb2 + sb3);\n    }\n";
+        const std::string sdirect = sd.str();
         o << R"SRC(
 struct CombArgs {
     const double *x;
@@ -537,26 +557,32 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     const int rho = tid * RPL;  // stage-B lane: its first residue (RPL residues per lane)
 
     // prologue: rows [-AHI, -ALO + NR) -> slots OFS - AHI .. (everything iteration 0 reads), 16-byte chunks
+    {
+        const long long p_lo = s0 - (long long)AHI * Q - HB;  // first sample of the fill
+        if (p_lo >= lim_lo && p_lo + (long long)(AHI - ALO + NR - 1) * Q + NCOL <= lim_hi) {
+            // every row is addressable (all stretches but the first and the last of a recording): 16-byte buffer
+            // loads, all in flight together
+            const u32 soff = (u32)((p_lo - a.buf_first) * 8);
+#pragma unroll 3
+            for (int t = tid; t < (AHI - ALO + NR) * CH16; t += NTHREADS) {
+                const int row = t / CH16, c16 = t - row * CH16;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (u32)(row * (Q * 8) + c16 * 16), soff, 0);
+                *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = v;
+            }
+        } else {
 #pragma unroll 1
-    for (int t = tid; t < (AHI - ALO + NR) * CH16; t += NTHREADS) {
-        const int row = t / CH16, c16 = t - row * CH16;
-        const long long n = s0 + (long long)(row - AHI) * Q - HB + 2 * c16;
-        *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, n);
-    }
-    __syncthreads();
-    // running tap sum of row 0, evaluated tap by tap (thread = residue)
-    double S = 0.0, S1 = 0.0;
-    if (rho < Q) {
-#pragma unroll 1
-        for (int rr = 0; rr < N_RUNS; ++rr) {
-            const double *rowp = reinterpret_cast<const double *>(smem + (OFS - RUN_A[rr]) * PB) + (HB + rho);
-            for (int b = RUN_BLO[rr]; b <= RUN_BHI[rr]; ++b) {
-                S += rowp[-b];
-                if (RPL == 2) S1 += rowp[1 - b];
+            for (int t = tid; t < (AHI - ALO + NR) * CH16; t += NTHREADS) {
+                const int row = t / CH16, c16 = t - row * CH16;
+                const long long n = p_lo + (long long)row * Q + 2 * c16;
+                *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, n);
             }
         }
     }
-    // stage-A lane: wave set hs takes its half of the delta units for row r of the iteration, residues [l*CC, l*CC + CC)
+    __syncthreads();
+    // running tap sum of row 0, evaluated tap by tap (thread = residue)
+)SRC";
+        o << sdirect;
+        o << R"SRC(    // stage-A lane: wave set hs takes its half of the delta units for row r of the iteration, residues [l*CC, l*CC + CC)
     const int hs = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int gi = (tid & 255) >> 4, l = tid & 15;
     const int r = (gi >> 2) + 4 * (gi & 3);
@@ -875,10 +901,11 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     // a_hi - a_lo + 2 NR rows and one tap-by-tap evaluation (~ 5 rows' worth).  Long recordings: ~1 M samples.
     const int64_t q = g.q;
     const int64_t prologue_rows = g.a_hi - g.a_lo + 2 * kNR + 8;
-    // Equal stretches: a recording is cut into round(length / ~0.9 M) stretches of the same number of rows (the
-    // last one a little shorter), not into 1 M stretches plus a remainder -- 10 M samples in 1 M stretches left a
-    // tenth round with half-empty workgroups (8.45 -> 8.25 ms).
-    int64_t target = 917504;
+    // Equal stretches: a recording is cut into round(length / ~1.6 M) stretches of the same number of rows (the
+    // last one a little shorter), not into fixed-size stretches plus a remainder -- 10 M samples in 1 M stretches
+    // left a tenth round with half-empty workgroups (8.45 -> 8.25 ms).  5 ... 12 equal stretches per 10 M-sample
+    // channel all run within 1.5 % of each other; 6 measured best (every stretch pays one prologue and one drain).
+    int64_t target = 1677722;
     if (const char *env = getenv("PARRM_COMB_STRETCH")) target = std::max<int64_t>(atoll(env), q * kNR);
     const int64_t n_cut = std::max<int64_t>(1, (a.out_len + target / 2) / target);
     int64_t rows = std::max<int64_t>(kNR, (((a.out_len + n_cut - 1) / n_cut + q - 1) / q + kNR - 1) / kNR * kNR);
