@@ -458,8 +458,6 @@ int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStr
         if constexpr (sizeof(TI) == 8 && sizeof(TO) == 8) {
             if (const CombKernel *ck = comb_for_launch(p, a)) return launch_comb(ck, args, stream);
         }
-        // the three-residues-per-lane form where the plan has one (PARRM_PHASE3=0 at plan time turns it off)
-        if (p->phase3.n_groups > 0) return launch_phase3<TI, TO>(p->phase3, p->d_phase3_tab, args, stream);
         return launch_phase<TI, TO>(p, args, stream);
     }
     if (kernel == PARRM_KERNEL_GATHER) {
@@ -650,9 +648,6 @@ static int build_plan(const std::vector<int8_t> &tap, int64_t hw, bool allow_seg
     std::vector<int32_t> phase_tab;
     plan_phase(tap, hw, p, &phase_tab);
     phase_tab.push_back(0);
-    std::vector<int32_t> phase3_tab;
-    if (!plan_phase3(tap, hw, p->phase, &p->phase3, &phase3_tab)) p->phase3 = Phase3Geom{};
-    phase3_tab.push_back(0);
 
     std::vector<int32_t> tables(runs);
     p->off_tapcum = static_cast<int64_t>(tables.size());
@@ -662,12 +657,11 @@ static int build_plan(const std::vector<int8_t> &tap, int64_t hw, bool allow_seg
     tables.push_back(0);
     // one device allocation: weights | tables | phase table
     const size_t wb = weights.size() * sizeof(double), tb = (tables.size() * sizeof(int32_t) + 7) & ~size_t{7},
-                 pb = phase_tab.size() * sizeof(int32_t), p3b = phase3_tab.size() * sizeof(int32_t);
-    std::vector<unsigned char> blob(wb + tb + pb + p3b);
+                 pb = phase_tab.size() * sizeof(int32_t);
+    std::vector<unsigned char> blob(wb + tb + pb);
     std::memcpy(blob.data(), weights.data(), wb);
     std::memcpy(blob.data() + wb, tables.data(), tables.size() * sizeof(int32_t));
     std::memcpy(blob.data() + wb + tb, phase_tab.data(), pb);
-    std::memcpy(blob.data() + wb + tb + pb, phase3_tab.data(), p3b);
     hipError_t e = hipGetDevice(&p->device);
     void *d_blob = nullptr;
     if (e == hipSuccess) e = hipMalloc(&d_blob, blob.size());
@@ -680,7 +674,6 @@ static int build_plan(const std::vector<int8_t> &tap, int64_t hw, bool allow_seg
     p->d_weights = static_cast<double *>(d_blob);
     p->d_tables = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb);
     p->d_phase_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb);
-    p->d_phase3_tab = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(d_blob) + wb + tb + pb);
     if (allow_segments && p->phase.n_groups == 0 && p->q == 0) build_segments(tap, hw, p);
     if (allow_segments) p->tap_mask = tap;  // (sub-plans of a segmented filter never take the generated kernel)
     *plan = p;
@@ -715,13 +708,6 @@ int parrm_filter_plan_query(const parrm_filter_plan *plan, parrm_filter_plan_inf
     info->phase_row_slots = plan->phase.m_slots;
     info->phase_residues = 1;
     info->reserved = static_cast<int32_t>(plan->segments.size());  // passes of a segmented plan (0: not segmented)
-    if (plan->phase3.n_groups > 0) {  // what a PHASE launch actually runs
-        info->phase_delta = 2 * plan->phase3.n_pairs;
-        info->phase_groups = plan->phase3.n_groups;
-        info->phase_rows = 2;
-        info->phase_row_slots = plan->phase3.m_slots;
-        info->phase_residues = 3;
-    }
     return PARRM_OK;
 }
 

@@ -154,30 +154,6 @@ struct PhaseGeom {
     const int32_t *tab;   // [M][2*d_pad] tap offsets per table row; [3*n_runs] (a', b_lo, b_hi); wrap: [2*d_pad] b
 };
 
-// ---------------------------------------------------------------- phase3 kernel geometry (3 residues per lane)
-constexpr int kP3MaxWide = 8;  // widest unit (columns read: width + 2), and the most wide units per filter
-struct Phase3Geom {
-    int32_t q, guard, n_res;   // stride, mirrored residues per side, columns of the ring (q + 2*guard)
-    int32_t lanes;             // threads per row group (whole waves; 3*lanes >= n_res)
-    int32_t m_slots, rs;       // ring rows; column stride in elements (odd, >= m_slots + 1; template constant)
-    int32_t n_groups;          // NG
-    int32_t a_lo, a_hi;        // tap rows reach from m - a_hi to m - a_lo
-    int32_t n_pairs;           // (+1, -1) single-tap pairs, padded (template constant)
-    int32_t n_wide;            // wide units
-    int32_t wide_w[kP3MaxWide];      // widths 1..kP3MaxWide
-    int32_t wide_sign[kP3MaxWide];   // +1 / -1
-    int32_t n_runs;
-    int32_t row_len;           // table row length: 2*n_pairs + n_wide
-    int32_t debug;             // profiling ablations (PARRM_P3_DEBUG): 1 no single taps, 2 no wide units, 4 no stores, 8 general path only, 16 no loads; results wrong by construction
-    const int32_t *tab;        // [m_slots][row_len] element offsets | [3*n_runs] (a', b_lo, b_hi)
-};
-
-
-// parrm_filter_phase3.hip
-bool plan_phase3(const std::vector<int8_t> &tap, int64_t hw, const PhaseGeom &phase, Phase3Geom *out,
-                 std::vector<int32_t> *table);
-template <typename TI, typename TO>
-int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, hipStream_t stream);
 }  // namespace parrm_filter
 
 namespace parrm_filter {
@@ -212,9 +188,6 @@ struct parrm_filter_plan {
     // its table holds BYTE offsets and lives behind the main one in d_phase_tab
     parrm_filter::PhaseGeom phase_pack{};
     int32_t *d_phase_tab = nullptr;
-    // three-residues-per-lane form of the phase kernel (n_groups == 0: not available for this filter)
-    parrm_filter::Phase3Geom phase3{};
-    int32_t *d_phase3_tab = nullptr;
     // Segmented form (half-widths beyond any LDS ring; parrm_filter.hip): the taps cut into windows of
     // offsets, each a plan of its own whose phase kernel adds its raw tap sums into a float64 accumulator.
     // seg_centre[k] is the offset w the k-th sub-plan's centre stands for.  Empty: not segmented.
@@ -235,9 +208,4 @@ void plan_phase(const std::vector<int8_t> &tap, int64_t hw, parrm_filter_plan *p
 // mode 0: y = x - mean of taps; TO = double only: mode 1: y += raw tap sum (a segment of a long filter), mode 2: y = it
 template <typename TI, typename TO>
 int launch_phase(const parrm_filter_plan *plan, FilterArgs *a, hipStream_t stream, int mode = 0);
-// parrm_filter_phase3.hip
-bool plan_phase3(const std::vector<int8_t> &tap, int64_t hw, const PhaseGeom &phase, Phase3Geom *out,
-                 std::vector<int32_t> *table);
-template <typename TI, typename TO>
-int launch_phase3(const Phase3Geom &geom, const int32_t *d_tab, FilterArgs *a, hipStream_t stream);
 }  // namespace parrm_filter

@@ -21,7 +21,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KNOBS = ("PARRM_PHASE_SHAPE", "PARRM_STRETCH_SAMPLES", "PARRM_PHASE3", "PARRM_NO_F32_PACK", "PARRM_PHASE_FORCE_WRAP")
+KNOBS = ("PARRM_PHASE_SHAPE", "PARRM_STRETCH_SAMPLES", "PARRM_NO_F32_PACK", "PARRM_PHASE_FORCE_WRAP")
 
 
 def draw_cases(n_cases: int, seed: int):
@@ -64,7 +64,6 @@ def draw_cases(n_cases: int, seed: int):
         env = {
             "PARRM_PHASE_SHAPE": str(rng.choice(["", "", "4,2", "2,4", "2,3", "3,2", "2,2", "1,4"])),
             "PARRM_STRETCH_SAMPLES": str(rng.choice(["", "", "20000", "60000"])),
-            "PARRM_PHASE3": "1" if rng.random() < 0.2 else "",
             "PARRM_NO_F32_PACK": "1" if rng.random() < 0.15 else "",
             "PARRM_PHASE_FORCE_WRAP": "1" if rng.random() < 0.15 else "",
         }

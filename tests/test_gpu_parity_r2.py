@@ -591,34 +591,6 @@ def test_dead_channel_does_not_trigger_the_repair_recompute():
 
 
 # ---------------------------------------------------------------------------- opt-in kernel form
-@pytest.mark.parametrize("dtype,out_dtype", [(np.float64, None), (np.float32, None), (np.float32, "f32")])
-def test_phase3_kernel_form_matches_the_oracle(monkeypatch, dtype, out_dtype):
-    """The three-residues-per-lane form of the phase kernel (PARRM_PHASE3=1 when the plan is built; opt-in
-    because it measured slower) must give the oracle's answer wherever it is selected:
-    default comb filter, one-sided filters, omitted centre, recording edges, a window call, ragged sizes."""
-    monkeypatch.setenv("PARRM_PHASE3", "1")
-    period = 169.23584615384616
-    for direction, omit, n in (("both", 0, 300_017), ("past", 0, 150_000), ("future", 3, 99_991), ("both", 40, 64_000)):
-        hw = orc.default_filter_half_width(n, period, omit, period / 50)
-        filt = orc.generate_filter(period, hw, omit, direction, None)
-        x = synth_recording(3, n, 22000, 130, seed=31).astype(dtype)
-        plan = _hip.FilterPlan(filt)
-        assert plan.info.phase_residues == 3, "the phase3 plan was not selected"
-        plan.set_kernel(_hip.KERNEL_PHASE)
-        t_out = torch.float32 if out_dtype == "f32" else torch.float64
-        y = plan.apply(torch.from_numpy(x).cuda(), out_dtype=t_out).cpu().numpy().astype(np.float64)
-        ref = orc.filter_data_direct(x, filt)
-        tol = 1e-10 if dtype == np.float64 else (2e-6 if out_dtype == "f32" else 1e-6)
-        assert np.abs(y - ref).max() <= tol * np.abs(ref).max(), (direction, omit, n)
-        if dtype == np.float64:  # a window of the same recording through the same form
-            o0, olen = n // 3 + 1, n // 4
-            b0, b1 = max(o0 - hw, 0), min(o0 + olen + hw, n)
-            part = plan.apply_window(torch.from_numpy(np.ascontiguousarray(x[:, b0:b1])).cuda(), b0, o0, olen, n).cpu().numpy()
-            assert np.abs(part - ref[:, o0:o0 + olen]).max() <= tol * np.abs(ref).max()
-    monkeypatch.delenv("PARRM_PHASE3")
-    assert _hip.FilterPlan(filt).info.phase_residues == 1  # opt-in only
-
-
 def test_channel_blocks_are_cut_like_the_whole_recording():
     """The launch picks its stretch length from the channel count (short or narrow recordings get fewer,
     longer stretches), so a channel block filtered on its own would be cut differently from the whole
