@@ -52,6 +52,8 @@ _STAGE_LAMBDA = 1.0
 _SMALL_GRID = 512
 # above this size a host recording is streamed through the device instead of cached on it
 _DEVICE_CACHE_BYTES = 96 << 30
+_PIPELINE_BYTES = 256 << 20        # host recordings from this size on are filtered in overlapped channel blocks
+_PIPELINE_BLOCK_BYTES = 256 << 20  # ... of about this size
 
 
 def _is_number(value) -> bool:
@@ -638,6 +640,9 @@ class PARRM:
         try:
             if isinstance(data, np.ndarray) and (isinstance(data, np.memmap) or data.nbytes > _DEVICE_CACHE_BYTES):
                 filtered = self._plan_for(None).apply_host(np.ascontiguousarray(data))
+            elif (isinstance(data, np.ndarray) and data.nbytes >= _PIPELINE_BYTES and data.shape[0] >= 2
+                  and type(self)._total_chans is PARRM._total_chans and not (self.cache_on_device and data is self._data)):
+                filtered = self._filter_host_pipelined(data)
             else:
                 x = self._device_recording(data)
                 y = self._plan_for(x.device).apply(x, total_chans=self._total_chans(x))
@@ -647,6 +652,47 @@ class PARRM:
         self._filtered_data = filtered
         self._say("    ... Data filtered\n")
         return self._filtered_data
+
+    def _filter_host_pipelined(self, data: np.ndarray) -> np.ndarray:
+        """NumPy in -> NumPy out for a large host recording (the reference's calling convention, parrm.py:835-875:
+        ndarray in, fresh ndarray out): contiguous channel blocks travel host -> device -> kernel -> page-locked
+        result on two alternating streams, so the upload of block k + 1 (a pageable copy, driven by this thread)
+        overlaps the kernel and the read-back of block k.  Channels are independent (:861-866) and every block is
+        cut like the whole recording (``total_chans``), so the result equals the one-piece call bit for bit."""
+        torch = _hip.require_gpu()
+        n_chans, n_samples = data.shape
+        plan = self._plan_for(None)
+        dev = torch.device("cuda", plan.device)
+        n_blocks = max(2, min(n_chans, -(-data.nbytes // _PIPELINE_BLOCK_BYTES)))
+        base, extra = divmod(n_chans, n_blocks)
+        bounds, lo = [], 0
+        for b in range(n_blocks):
+            hi = lo + base + (1 if b < extra else 0)
+            bounds.append((lo, hi))
+            lo = hi
+        rows_max = bounds[0][1] - bounds[0][0]
+        in_dtype = torch.float32 if data.dtype == np.float32 else torch.float64
+        try:
+            out = torch.empty((n_chans, n_samples), dtype=torch.float64, pin_memory=True)
+        except RuntimeError:  # the host's page-lock limit
+            out = torch.empty((n_chans, n_samples), dtype=torch.float64)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        x_d = [torch.empty((rows_max, n_samples), dtype=in_dtype, device=dev) for _ in range(2)]
+        y_d = [torch.empty((rows_max, n_samples), dtype=torch.float64, device=dev) for _ in range(2)]
+        for st in streams:  # the buffers above were allocated on the current stream
+            st.wait_stream(torch.cuda.current_stream(dev))
+        for k, (lo, hi) in enumerate(bounds):
+            rows, b = hi - lo, k & 1
+            block = data[lo:hi]
+            if block.dtype not in (np.float32, np.float64):
+                block = block.astype(np.float64)
+            with torch.cuda.stream(streams[b]):
+                x_d[b][:rows].copy_(torch.from_numpy(np.ascontiguousarray(block)), non_blocking=True)
+                plan.apply(x_d[b][:rows], out=y_d[b][:rows], total_chans=n_chans)
+                out[lo:hi].copy_(y_d[b][:rows], non_blocking=True)
+        for st in streams:
+            st.synchronize()
+        return out.numpy()
 
     def online(self, n_chans=None, dtype=None, out_dtype=np.float64, device=None):
         """Stateful block-by-block filtering with the current filter (``streaming.OnlineFilter``):

@@ -133,3 +133,26 @@ def test_filter_host_sharded_blocks_are_views_of_one_large_array():
     # and again: the first call's lock was released, nothing is left registered
     y2 = sharding.filter_host_sharded(filt, x, devices=[0, 0, 0])
     assert np.abs(y2 - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.float16])
+def test_numpy_caller_pipeline_equals_the_one_piece_call(monkeypatch, dtype):
+    """The reference's calling convention (ndarray in, fresh ndarray out, parrm.py:835-875) on a host array large
+    enough for the overlapped channel-block pipeline (threshold lowered here): same bits as the one-piece call,
+    float64 out for any input type, uneven blocks."""
+    from pyparrm_amd import parrm as facade
+
+    fs, fa = 22000.0, 130.0
+    x = synth_recording(7, 300_000, fs, fa, seed=51).astype(dtype)
+    p = PARRM(x, fs, fa, verbose=False)
+    p._period = np.float64(fs / fa * (1 + 3e-5))
+    p.create_filter()
+    monkeypatch.setattr(facade, "_PIPELINE_BYTES", 1 << 60)
+    whole = p.filter_data()
+    monkeypatch.setattr(facade, "_PIPELINE_BYTES", 1 << 20)
+    monkeypatch.setattr(facade, "_PIPELINE_BLOCK_BYTES", x.nbytes // 3)
+    piped = p.filter_data()
+    assert piped.dtype == np.float64 and piped is not whole and np.array_equal(piped, whole)
+    ref = orc.filter_data_direct(x.astype(np.float64), p.filter)
+    tol = 1e-10 if dtype == np.float64 else 1e-6
+    assert np.abs(piped - ref).max() <= tol * np.abs(ref).max()
