@@ -153,6 +153,12 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
  * it generates the kernel for a filter array and writes <out_dir>/comb_<hash>.hsaco (and its source, whose
  * path is returned in source_path when that is not NULL).  `stride` 0 = the stride a plan would choose.
  * PARRM_ERR_INVALID when the generated form does not take this filter (such filters run the generic kernels). */
+/* Measurement aid: with `enable` != 0 every later parrm_filter_apply* call of the calling thread records HIP events
+ * on its stream right around its MAIN kernel (not the non-finite repair pass behind it); `last_ms` (may be NULL)
+ * receives the duration of the most recent such kernel, waiting for it to finish (-1 when there is none).
+ * enable == 0 releases the events. */
+int parrm_filter_kernel_timing(int enable, float *last_ms);
+
 /* Has this plan's generated kernel been used?  state: 0 = no launch large enough yet (or PARRM_COMB=0),
  * 1 = generated, loaded, self-tested against the tap-by-tap kernel and in use for float64 launches,
  * -1 = not available for this filter (message says why; the generic kernels run instead). */

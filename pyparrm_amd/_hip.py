@@ -36,6 +36,7 @@ SYMBOLS = (
     "parrm_filter_host",
     "parrm_filter_comb_precompile",
     "parrm_filter_plan_generated",
+    "parrm_filter_kernel_timing",
     "parrm_host_pin",
     "parrm_host_unpin",
     "parrm_absdiff_workspace_bytes",
@@ -151,6 +152,7 @@ def lib() -> C.CDLL:
         L.parrm_filter_plan_set_kernel.restype = i32
         L.parrm_filter_plan_set_kernel.argtypes = [vp, i32]
         L.parrm_filter_plan_generated.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+        L.parrm_filter_kernel_timing.argtypes = [i32, C.POINTER(C.c_float)]
         L.parrm_filter_comb_precompile.argtypes = [vp, i64, i64, C.c_char_p, C.c_char_p, C.c_size_t]
         L.parrm_filter_apply.restype = i32
         L.parrm_filter_apply.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
@@ -432,6 +434,14 @@ class FilterPlan:
 _PLAN_CACHE: dict = {}
 _PLAN_CACHE_SIZE = 16
 _PLAN_CACHE_LOCK = threading.Lock()
+
+
+def filter_kernel_timing(enable: bool) -> float:
+    """Switch the library's own event bracket around the MAIN filter kernel on or off for this thread; returns the
+    duration in ms of the most recent bracketed kernel (-1.0 when there is none)."""
+    ms = C.c_float(-1.0)
+    check(lib().parrm_filter_kernel_timing(1 if enable else 0, C.byref(ms)), "filter_kernel_timing")
+    return float(ms.value)
 
 
 def precompile_filter_kernel(filt: np.ndarray, out_dir: str | None = None, stride: int = 0) -> str:

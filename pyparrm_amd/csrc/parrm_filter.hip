@@ -440,10 +440,21 @@ int launch_segmented(const parrm_filter_plan *p, FilterArgs a, hipStream_t strea
     return PARRM_OK;
 }
 
+// parrm_filter_kernel_timing: HIP events right around the MAIN kernel of a launch (not the repair pass behind it),
+// on the launch's own stream -- what bench.py's `roofline` is computed from.
+struct KernelTiming {
+    bool enabled = false, recorded = false;
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+thread_local KernelTiming *g_timing = nullptr;  // (a trivially destructible pointer: nothing runs at thread exit)
+
 template <typename TI, typename TO>
 int launch(const parrm_filter_plan *p, FilterArgs a, int kernel, hipStream_t stream) {
     if (kernel == PARRM_KERNEL_SEGMENTED) return launch_segmented<TI, TO>(p, a, stream);
+    KernelTiming *t = g_timing && g_timing->enabled ? g_timing : nullptr;
+    if (t) (void)hipEventRecord(t->start, stream);
     const int rc = launch_main<TI, TO>(p, &a, kernel, stream);
+    if (t) t->recorded = hipEventRecord(t->stop, stream) == hipSuccess;
     if (rc != PARRM_OK || kernel == PARRM_KERNEL_GATHER || getenv("PARRM_NO_REPAIR_PASS")) return rc;
     const int64_t blocks = (a.n_chans * a.n_stretch + kRepairStretchesPerBlock - 1) / kRepairStretchesPerBlock;
     hipLaunchKernelGGL((filter_repair_kernel<TI, TO>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, a);
@@ -717,6 +728,30 @@ int parrm_filter_plan_generated(const parrm_filter_plan *plan, int *state, int *
     *state = plan->comb_state;
     if (stride) *stride = plan->comb ? comb_stride(plan->comb) : 0;
     if (message && message_len) snprintf(message, message_len, "%s", plan->comb ? comb_error(plan->comb) : "");
+    return PARRM_OK;
+}
+
+int parrm_filter_kernel_timing(int enable, float *last_ms) {
+    if (!g_timing) g_timing = new KernelTiming();
+    KernelTiming &t = *g_timing;
+    if (last_ms) {
+        *last_ms = -1.0f;
+        if (t.recorded) {
+            PARRM_HIP_CHECK(hipEventSynchronize(t.stop));
+            PARRM_HIP_CHECK(hipEventElapsedTime(last_ms, t.start, t.stop));
+        }
+    }
+    if (enable && !t.start) {
+        PARRM_HIP_CHECK(hipEventCreate(&t.start));
+        PARRM_HIP_CHECK(hipEventCreate(&t.stop));
+    }
+    if (!enable && t.start) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+        t.start = t.stop = nullptr;
+        t.recorded = false;
+    }
+    t.enabled = enable != 0;
     return PARRM_OK;
 }
 
