@@ -383,10 +383,19 @@ const CombKernel *comb_for_launch(const parrm_filter_plan *p, const FilterArgs &
             return nullptr;
         }
         p->comb_state = -1;
-        if (p->comb) {
-            if (comb_load(p->comb) && comb_self_test(p)) p->comb_state = 1;
-            else if (getenv("PARRM_COMB_VERBOSE")) fprintf(stderr, "parrm: generated filter kernel unavailable: %s\n", comb_error(p->comb));
+        // a build that spills registers is refused at load time: leaner variants (smaller read batches) are tried
+        for (int attempt = 0; p->comb; ++attempt) {
+            if (comb_load(p->comb)) {
+                if (comb_self_test(p)) p->comb_state = 1;
+                break;
+            }
+            CombKernel *next = strstr(comb_error(p->comb), "scratch") ? comb_generate(p->tap_mask, p->hw, q, attempt + 1) : nullptr;
+            if (!next) break;
+            comb_destroy(p->comb);
+            p->comb = next;
         }
+        if (p->comb && p->comb_state != 1 && getenv("PARRM_COMB_VERBOSE"))
+            fprintf(stderr, "parrm: generated filter kernel unavailable: %s\n", comb_error(p->comb));
     }
     if (p->comb_state != 1 || !comb_accepts(p->comb, a)) return nullptr;
     return p->comb;

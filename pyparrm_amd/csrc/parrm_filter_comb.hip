@@ -820,12 +820,16 @@ struct CombKernel {
 };
 
 // Geometry + source for a tap mask (no device needed); nullptr when this kernel cannot take the filter.
-CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q) {
+// `attempt` > 0: leaner variants for geometries whose first build spills registers (smaller read batches keep
+// fewer values in flight): the caller walks 0, 1, 2 until a build has no scratch.
+CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt) {
     Geom g;
     if (!make_geom(tap, hw, q, &g)) return nullptr;
+    if (attempt > 2) return nullptr;
     auto *k = new CombKernel();
     k->geom = g;
-    k->source = Emitter(k->geom, pick_batch()).source();
+    const int batch = attempt == 0 ? pick_batch() : attempt == 1 ? 5 : 4;
+    k->source = Emitter(k->geom, batch).source();
     return k;
 }
 
@@ -978,7 +982,7 @@ int parrm_filter_comb_precompile(const double *h_filter, int64_t filter_len, int
     for (int64_t i = 0; i < filter_len; ++i)
         if (i != hw && h_filter[i] != 0.0) tap[i] = 1;
     if (stride == 0) stride = parrm_filter::comb_search_stride(tap, hw);
-    parrm_filter::CombKernel *k = stride ? parrm_filter::comb_generate(tap, hw, stride) : nullptr;
+    parrm_filter::CombKernel *k = stride ? parrm_filter::comb_generate(tap, hw, stride, 0) : nullptr;
     if (!k) {
         parrm::set_error("comb_precompile: the generated kernel does not take this filter");
         return PARRM_ERR_INVALID;

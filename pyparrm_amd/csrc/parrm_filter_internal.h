@@ -159,7 +159,7 @@ struct PhaseGeom {
 namespace parrm_filter {
 // parrm_filter_comb.hip: the per-filter generated kernel (float64 recordings, comb filters with q in [80, 176])
 struct CombKernel;
-CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q);
+CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt = 0);
 void comb_destroy(CombKernel *k);
 bool comb_load(CombKernel *k);  // code object from the caches or hipRTC, loaded on the current device
 const char *comb_error(const CombKernel *k);
