@@ -76,8 +76,13 @@ for r in csv.DictReader(open(trace)):
 with open(os.path.join(dst, f"{tag}_filter_kernel_launches.txt"), "w") as fh:
     fh.write("# filter kernel launches in the rocprofv3 kernel trace of the default bench command, by (kernel, grid size)\n")
     for (name, grid), v in sorted(durs.items(), key=lambda kv: -max(kv[1])):
-        line = f"{name:<42} grid {grid:>9}  launches {len(v):>3}  avg {sum(v) / len(v):8.3f} ms  min {min(v):8.3f}  max {max(v):8.3f}"
-        fh.write(line + "\n")
-        print(line)
+        # one grid size can serve two shapes (256 workgroups: 256 ch x 10 M in one stretch per channel, and 64 ch x 1 M
+        # in four): split by duration
+        for label, part in (("long", [d for d in v if d > 0.5 * max(v)]), ("short", [d for d in v if d <= 0.5 * max(v)])):
+            if part:
+                line = (f"{name:<42} grid {grid:>9} {label:<5} launches {len(part):>3}  avg {sum(part) / len(part):8.3f} ms  "
+                        f"min {min(part):8.3f}  max {max(part):8.3f}")
+                fh.write(line + "\n")
+                print(line)
 for r in ours[:12]:
     print(f"{r[0][:90]:<92} calls {r[1]:>5}  avg {float(r[3]) / 1e3:>10.1f} us  {r[4]:>6} %")
