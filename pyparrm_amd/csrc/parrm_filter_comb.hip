@@ -117,6 +117,10 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     }
     if (guard > 12) return false;
     g->hb = guard;
+    // the ring always holds the rows of the current iteration themselves (stage B reads its own samples there), also
+    // when every tap lies on one side of the centre (one-sided filters with omitted samples: found by the self-test)
+    g->a_hi = std::max(g->a_hi, 0);
+    g->a_lo = std::min(g->a_lo, 0);
     // units: maximal groups of adjacent offsets with one sign inside one row
     for (size_t i = 0; i < delta.size();) {
         const int a = floordiv_round(delta[i].first, q);

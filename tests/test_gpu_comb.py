@@ -201,3 +201,21 @@ def test_generated_kernel_full_size_launches_are_deterministic_and_match_sampled
         hw = (filt.size - 1) // 2
         got = first[ch:ch + 1, 4_000_000 + hw:4_600_000 - hw].cpu().numpy()
         assert np.abs(got - ref[:, hw:-hw]).max() <= TOL * scale
+
+
+def test_generated_kernel_one_sided_filters_with_omitted_samples(monkeypatch):
+    """Found by the kernel's own first-use self-test (scripts/exp_comb_selftest.py): with `filter_direction="past"` and
+    omitted samples every tap lies on one side of the centre and no tap row coincides with the rows of the current
+    iteration, which the ring must hold all the same (stage B reads its own samples there).  Before the fix such
+    filters failed the self-test and fell back to the generic kernel; now they run the generated one."""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    rng = np.random.default_rng(23)
+    for period, hw, omit, direction in ((101.77, 650, 7, "past"), (123.08, 2372, 29, "past"), (169.2359, 2372, 7, "past"),
+                                        (169.2359, 2372, 29, "future")):
+        filt = orc.generate_filter(period, hw, omit, direction, period / 50)
+        x = rng.standard_normal((2, 150_001))
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+        _in_use(plan, may_decline=True)
+        ref = orc.filter_data_direct(x, filt)
+        assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), (period, hw, omit, direction)
