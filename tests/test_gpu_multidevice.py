@@ -156,3 +156,22 @@ def test_numpy_caller_pipeline_equals_the_one_piece_call(monkeypatch, dtype):
     ref = orc.filter_data_direct(x.astype(np.float64), p.filter)
     tol = 1e-10 if dtype == np.float64 else 1e-6
     assert np.abs(piped - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_fit_error_slices_of_at_most_64_candidates_match_the_whole_grid_bitwise():
+    """a slice of <= 64 candidates at K = 41 takes the one-wave-per-quarter solve (+ fit_finish_kernel),
+    the whole grid the four-wave form -- 8 ranks x ~48 stage-3 candidates is exactly the 8-GPU strong-scaling shape.
+    Same bits required, 256 channels."""
+    rng = np.random.default_rng(4)
+    n_idx, n_chans = 6000, 256
+    idx = np.sort(rng.choice(60_000, size=n_idx, replace=False)).astype(np.int64)
+    y = torch.from_numpy(rng.standard_normal((n_idx, n_chans))).cuda()
+    d_idx = torch.from_numpy(idx).cuda()
+    grid = 169.2358 * (1 + np.linspace(-1e-3, 1e-3, 381))
+    for bw in (20, 10, 5):
+        whole = _hip.fit_errors(y, d_idx, grid, bw, 1.0)
+        for world in (8, 6):
+            parts = [_hip.fit_errors(y, d_idx, grid[lo:hi], bw, 1.0, grid_periods=grid.shape[0])
+                     for lo, hi in sharding.even_split(grid.shape[0], world)]
+            assert max(len(p) for p in parts) <= 64
+            assert np.array_equal(np.concatenate(parts), whole), (bw, world)
