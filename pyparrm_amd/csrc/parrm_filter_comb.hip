@@ -923,7 +923,12 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
         double best = 1e300;
         int64_t best_rows = rows;
         const int64_t max_stretches = std::max<int64_t>(1, a.out_len / (static_cast<int64_t>(4) * kNR * q));
-        for (int64_t per_chan = 1; per_chan <= std::min<int64_t>(max_stretches, 4096); ++per_chan) {
+        // At least 8 stretches per channel on long recordings: the cut is planned for the WHOLE recording (a channel
+        // block of a sharded run must be cut the same way to return the same bits), so one stretch per channel --
+        // optimal for 256 channels on one GPU -- would leave a 32-channel shard of an 8-GPU run with 32 workgroups
+        // for 256 CUs.  5 ... 12 equal stretches per channel measure within 1.5 % of each other.
+        const int64_t min_stretches = std::min<int64_t>(8, std::max<int64_t>(1, a.out_len / (int64_t{1} << 20)));
+        for (int64_t per_chan = std::min(min_stretches, max_stretches); per_chan <= std::min<int64_t>(max_stretches, 4096); ++per_chan) {
             const int64_t r = ((a.out_len + per_chan - 1) / per_chan + q - 1) / q;
             const int64_t rr = (r + kNR - 1) / kNR * kNR;
             const int64_t blocks = blocks_for(rr);

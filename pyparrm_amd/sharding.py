@@ -191,7 +191,7 @@ class ShmExchange(Exchange):
         self._dist = dist
         self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
         self._group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
-        self._tag = tag or f"parrm{os.environ.get('MASTER_PORT', '0')}"
+        self._tag = tag or f"parrm{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self._mine = None          # (SharedMemory, capacity)
         self._theirs = {}          # rank -> (SharedMemory, capacity)
         self._seq = 0
@@ -208,7 +208,14 @@ class ShmExchange(Exchange):
                 self._mine[0].unlink()
             cap = max(nbytes, 1 << 20)
             name = f"{self._tag}_r{self.rank}_g{self._seq}"
-            self._mine = (shared_memory.SharedMemory(name=name, create=True, size=cap), cap, name)
+            try:
+                seg = shared_memory.SharedMemory(name=name, create=True, size=cap)
+            except FileExistsError:  # left behind by an earlier job that died with the same rendezvous port
+                stale = shared_memory.SharedMemory(name=name)
+                stale.close()
+                stale.unlink()
+                seg = shared_memory.SharedMemory(name=name, create=True, size=cap)
+            self._mine = (seg, cap, name)
         return self._mine
 
     def all_gather(self, tensor):
