@@ -69,10 +69,11 @@ def parse():
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 (default): the headline, resident f64 find_period + filter_data; cfg5: BASELINE "
                          "configs[4], float32 recording streamed from page-locked host memory, filter_data only")
-    ap.add_argument("--exchange", choices=["shm", "device", "host"], default="shm",
-                    help="strong mode under a launcher: the two exchanges per stage staged through POSIX shared memory "
-                         "(default: no RCCL in the data path; falls back to `device` if shared memory cannot be set up), "
-                         "on the process group's device collective (RCCL over xGMI with nccl), or through a gloo group")
+    ap.add_argument("--exchange", choices=["ipc", "shm", "device", "host"], default="ipc",
+                    help="strong mode under a launcher: the two exchanges per stage as device-to-device peer copies through "
+                         "IPC memory handles (default: no RCCL in the data path; falls back to `shm`, then `device`), staged "
+                         "through page-locked POSIX shared memory, on the process group's device collective (RCCL over xGMI "
+                         "with nccl), or through a gloo group")
     ap.add_argument("--spawn", action="store_true",
                     help="no launcher and --gpus N > 1: start N rank processes (default: ONE process, one host thread "
                          "per device -- sharding.MultiDevicePARRM)")
@@ -349,8 +350,16 @@ def main():
     if strong:
         lo, hi = channel_shard(n_chans, rank, world)
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=0, chan_range=(lo, hi))
-        exchange_name = args.exchange
-        if args.exchange == "shm":
+        exchange_name, exchange = args.exchange, None
+        if exchange_name == "ipc":
+            from pyparrm_amd.sharding import IpcExchange
+
+            exchange = IpcExchange.create(dist)  # None on EVERY rank if any rank cannot use IPC handles
+            if exchange is None:
+                if rank == 0:
+                    print("bench.py: IPC-handle exchange unavailable; using shared memory", file=sys.stderr)
+                exchange_name = "shm"
+        if exchange_name == "shm":
             try:
                 from pyparrm_amd.sharding import ShmExchange
 
@@ -358,9 +367,8 @@ def main():
             except Exception as exc:  # e.g. /dev/shm not writable: the device collective is the fallback
                 print(f"bench.py: shared-memory exchange unavailable ({exc}); using the device collective", file=sys.stderr)
                 exchange_name = "device"
-                exchange = TorchExchange(dist)
-        else:
-            exchange = TorchExchange(dist, via_host=args.exchange == "host")
+        if exchange is None:
+            exchange = TorchExchange(dist, via_host=exchange_name == "host")
     else:
         x = synth_recording_device(n_chans, n_samples, FS, F_ART, seed=1000 * rank)
     shared_rows = 0
@@ -429,7 +437,7 @@ def main():
         elif strong:
             parallelism = (f"one recording, channel blocks of {rows} rows on {world} GPUs; filter_data and the statistics "
                            "pass without exchange, candidate grids in per-rank slices over a replicated stage matrix "
-                           f"(2 exchanges per stage, {'staged through POSIX shared memory, no RCCL in the data path' if exchange_name == 'shm' else 'staged through host memory (gloo)' if exchange_name == 'host' or args.backend != 'nccl' else 'RCCL all_gather over xGMI'}), "
+                           f"(2 exchanges per stage, {'device-to-device peer copies through IPC memory handles, no RCCL in the data path' if exchange_name == 'ipc' else 'staged through page-locked POSIX shared memory, no RCCL in the data path' if exchange_name == 'shm' else 'staged through host memory (gloo)' if exchange_name == 'host' or args.backend != 'nccl' else 'RCCL all_gather over xGMI'}), "
                            "Nelder-Mead replicated")
         else:
             parallelism = f"{world} independent recordings, one per GPU, no exchange"

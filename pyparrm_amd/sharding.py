@@ -22,9 +22,12 @@ The exchange goes through an :class:`Exchange` object:
 * ``DeviceExchange`` -- N ranks as N host threads of ONE process, one device each, pieces moved by peer copies:
   what :class:`MultiDevicePARRM` (the single-process, NumPy-in / NumPy-out facade over all the GPUs of a node;
   SURVEY.md section 7 step 6: "one host thread + stream per device, no collectives") is built on;
-* ``ShmExchange`` -- one process per GPU (a launcher such as ``torch.distributed.run``), pieces staged through
-  POSIX shared memory: no RCCL anywhere in the data path (BASELINE.json's north_star), ``torch.distributed`` only
-  provides the barrier.  ``bench.py --gpus N`` uses it by default;
+* ``IpcExchange`` -- one process per GPU (a launcher such as ``torch.distributed.run``), pieces copied device to
+  device through IPC memory handles (peer copies over xGMI): no RCCL anywhere in the data path (BASELINE.json's
+  north_star), no host staging; ``torch.distributed`` only carries the handles and the barrier.  ``bench.py
+  --gpus N`` uses it by default;
+* ``ShmExchange`` -- the same processes, pieces staged through page-locked POSIX shared memory: the fallback where
+  IPC handles cannot be used;
 * ``TorchExchange`` -- the same processes, pieces by ``all_gather`` on the launcher's process group (RCCL over xGMI
   when its backend is nccl, host memory when it is gloo): the fallback when shared memory is not available;
 * ``ThreadExchange`` -- N thread-ranks on one device (tests).
@@ -194,6 +197,7 @@ class ShmExchange(Exchange):
         self._tag = tag or f"parrm{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self._mine = None          # (SharedMemory, capacity)
         self._theirs = {}          # rank -> (SharedMemory, capacity)
+        self._pinned = []          # (address, segment) of page-locked mappings
         self._seq = 0
 
     def _barrier(self):
@@ -216,7 +220,22 @@ class ShmExchange(Exchange):
                 stale.unlink()
                 seg = shared_memory.SharedMemory(name=name, create=True, size=cap)
             self._mine = (seg, cap, name)
+            self._pin(seg)
         return self._mine
+
+    def _pin(self, seg):
+        """Page-lock a segment's mapping for the life of the mapping (its own, page-aligned mmap; registered once,
+        never re-registered): copies to and from it then run at the link's rate instead of the pageable path's."""
+        import ctypes
+
+        import torch
+
+        try:
+            addr = ctypes.addressof(ctypes.c_char.from_buffer(seg.buf))
+            if int(torch.cuda.cudart().cudaHostRegister(addr, seg.size, 0)) == 0:
+                self._pinned.append((addr, seg))
+        except Exception:  # noqa: BLE001 -- not page-locked: merely slower
+            pass
 
     def all_gather(self, tensor):
         import torch
@@ -241,6 +260,7 @@ class ShmExchange(Exchange):
                 if cur is not None:
                     cur[0].close()
                 cur = (shared_memory.SharedMemory(name=name), name)
+                self._pin(cur[0])
                 try:  # (Python < 3.13 also registers ATTACHED segments with the resource tracker, which then
                     #  unlinks -- or warns about -- segments this process never owned)
                     from multiprocessing import resource_tracker
@@ -255,6 +275,14 @@ class ShmExchange(Exchange):
         return parts
 
     def close(self):
+        import torch
+
+        for addr, _seg in self._pinned:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(addr)
+            except Exception:  # noqa: BLE001
+                pass
+        self._pinned = []
         for seg in self._theirs.values():
             seg[0].close()
         self._theirs = {}
@@ -271,6 +299,84 @@ class ShmExchange(Exchange):
             self.close()
         except Exception:
             pass
+
+
+class IpcExchange(Exchange):
+    """One process per GPU, pieces moved DEVICE TO DEVICE without a collective library: every rank publishes an IPC
+    handle of its piece (``torch.multiprocessing.reductions.reduce_tensor``: hipIpcGetMemHandle + an interprocess
+    event), the handles travel as small pickled objects over a gloo group, and every rank copies the other ranks'
+    pieces straight into its own memory (peer copies over xGMI).  No RCCL anywhere in the data path and no host
+    staging; ``torch.distributed`` only carries the handles and the barrier.  Needs ``HSA_ENABLE_IPC_MODE_LEGACY=0``
+    on this platform (exported by the image) and peer access between the devices.
+
+    ``IpcExchange.create(dist)`` probes the mechanism on every rank and returns None -- on EVERY rank -- if any rank
+    cannot use it; callers then fall back to :class:`ShmExchange`."""
+
+    def __init__(self, dist, group):
+        self._dist, self._group = dist, group
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        self._mine = None    # this rank's exchange buffer (uint8 device tensor), mapped by every peer
+        self._peers = {}     # rank -> that rank's buffer as mapped into this process
+
+    @classmethod
+    def create(cls, dist):
+        import torch
+
+        group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+        ex = cls(dist, group)
+        ok = True
+        try:
+            probe = torch.full((1024,), float(ex.rank), dtype=torch.float64, device="cuda")
+            parts = ex.all_gather(probe)
+            ok = all(float(p[0].item()) == float(r) and float(p[-1].item()) == float(r) for r, p in enumerate(parts))
+        except Exception:  # noqa: BLE001 -- any failure means "not usable here"
+            ok = False
+        flags = [None] * ex.world_size
+        dist.all_gather_object(flags, bool(ok), group=group)
+        return ex if all(flags) else None
+
+    def _ensure(self, nbytes: int, device):
+        """Exchange buffers of at least `nbytes` on every rank (all ranks pass pieces of one size, so all grow
+        together): allocated once, their IPC handles exchanged once, the mappings kept -- an `all_gather` is then
+        copies and two barriers, no handle traffic."""
+        import torch
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        if self._mine is not None and self._mine.numel() >= nbytes:
+            return
+        self._peers = {}
+        self._mine = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        handles = [None] * self.world_size
+        self._dist.all_gather_object(handles, reduce_tensor(self._mine), group=self._group)
+        for rank, (rebuild, args) in enumerate(handles):
+            if rank != self.rank:
+                self._peers[rank] = rebuild(*args)
+
+    def all_gather(self, tensor):
+        import torch
+
+        src = tensor.contiguous()
+        if not src.is_cuda:
+            parts = [torch.empty_like(src) for _ in range(self.world_size)]
+            self._dist.all_gather(parts, src, group=self._group)
+            return parts
+        nbytes = src.numel() * src.element_size()
+        self._ensure(nbytes, src.device)
+        mine = self._mine[:nbytes].view(src.dtype).view(src.shape)
+        mine.copy_(src)
+        torch.cuda.current_stream(src.device).synchronize()
+        self._dist.barrier(group=self._group)  # every rank's piece is in its buffer
+        parts = []
+        for rank in range(self.world_size):
+            if rank == self.rank:
+                parts.append(src)
+            else:
+                remote = self._peers[rank][:nbytes].view(src.dtype).view(src.shape)
+                parts.append(remote.to(src.device, copy=True))  # device-to-device copy into our own memory
+        torch.cuda.current_stream(src.device).synchronize()
+        self._dist.barrier(group=self._group)  # nobody rewrites its buffer before every rank has copied it
+        return parts
 
 
 # ------------------------------------------------------------------------------ sharded facade

@@ -175,3 +175,62 @@ def test_fit_error_slices_of_at_most_64_candidates_match_the_whole_grid_bitwise(
                      for lo, hi in sharding.even_split(grid.shape[0], world)]
             assert max(len(p) for p in parts) <= 64
             assert np.array_equal(np.concatenate(parts), whole), (bw, world)
+
+
+_TWO_RANK_EXCHANGE = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PARRM_REPO"])
+from pyparrm_amd import PARRM, sharding
+from pyparrm_amd.synth import synth_recording_exact
+
+torch.cuda.set_device(0)  # both ranks on the one GPU of the box (a multi-GPU node gives each rank its own)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+kind = os.environ["PARRM_TEST_EXCHANGE"]
+ex = sharding.IpcExchange.create(dist) if kind == "ipc" else sharding.ShmExchange(dist)
+assert ex is not None, "IPC-handle exchange unavailable"
+for rows in (5, 70_000, 33):  # (growing pieces: the exchange buffers / segments are re-made once)
+    t = torch.arange(rows * 6, dtype=torch.float64, device="cuda").reshape(rows, 6) + 1000.0 * rank
+    parts = ex.all_gather(t)
+    assert len(parts) == world and all(p.is_cuda for p in parts)
+    for r, p in enumerate(parts):
+        assert torch.equal(p, torch.arange(rows * 6, dtype=torch.float64, device="cuda").reshape(rows, 6) + 1000.0 * r)
+fs, fa = 22000.0, 130.0
+x = synth_recording_exact(5, 60_000, fs / fa * (1 + 2e-5), seed=9)
+one = PARRM(x, fs, fa, verbose=False)
+one.find_period(random_seed=3)
+sh = sharding.ShardedPARRM(sharding.shard_recording(x, rank, world), fs, fa, ex, verbose=False)
+sh.find_period(random_seed=3)
+assert sh.period == one.period, (sh.period, one.period)
+sh.create_filter(); one.create_filter()
+lo, hi = sharding.channel_shard(5, rank, world)
+assert np.array_equal(sh.filter_data(), one.filter_data()[lo:hi])
+dist.barrier()
+if hasattr(ex, "close"):
+    ex.close()
+dist.destroy_process_group()
+print("TWO_RANK_EXCHANGE_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("kind", ["ipc", "shm"])
+def test_process_per_rank_exchanges_without_a_collective_library(kind):
+    """The launcher path's two RCCL-free exchanges, two rank PROCESSES (on the one GPU a test box has): device-to-device
+    copies through IPC memory handles (`IpcExchange`, bench.py's default) and page-locked shared memory
+    (`ShmExchange`); the sharded search on top lands on the single-process period, the blocks on its output."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29580 + (1 if kind == "ipc" else 2)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   PARRM_REPO=root, PARRM_TEST_EXCHANGE=kind, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANK_EXCHANGE], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"TWO_RANK_EXCHANGE_OK {rank}" in so, so[-1500:] + se[-3000:]
