@@ -52,6 +52,8 @@ _STAGE_LAMBDA = 1.0
 _SMALL_GRID = 512
 # above this size a host recording is streamed through the device instead of cached on it
 _DEVICE_CACHE_BYTES = 96 << 30
+_HALF_WIDTH_MEMO: dict = {}  # (limit, omit, period, period half-width) -> default filter half-width
+_FILTER_MEMO: dict = {}      # (half-width, period, period half-width, omit, direction) -> filter array (copied out)
 _PIPELINE_BYTES = 256 << 20        # host recordings from this size on are filtered in overlapped channel blocks
 _PIPELINE_BLOCK_BYTES = 256 << 20  # ... of about this size
 
@@ -406,12 +408,19 @@ class PARRM:
         )
         trace = []
         stage = None
+        # Every stage's sample indices and stage matrix are made NOW: they depend on the recording, its scale and
+        # the seed only (the reference draws stage 3's indices from the same generator at the same point of its
+        # sequence, parrm.py:284, :369-371), so the three gathers queue on the device right behind the statistics
+        # pass -- which the host would otherwise sit out -- instead of each waiting for the previous stage's
+        # optimiser while the device idles through 25 000 PCG64 draws and a sort.
+        plans = []
         for run, (use_n, ignore, bandwidth) in enumerate(
             zip(lengths, _STAGE_IGNORE, _STAGE_BANDWIDTHS), start=1
         ):
             indices = self._get_centre_indices(use_n, ignore, rng)
-            bandwidth = int(np.min((bandwidth, indices.shape[0] // 4)))
-            y, d_idx = self._stage_matrix(indices)
+            plans.append((run, indices, int(np.min((bandwidth, indices.shape[0] // 4)))))
+        matrices = [self._stage_matrix(indices) for _, indices, _ in plans]
+        for (run, indices, bandwidth), (y, d_idx) in zip(plans, matrices):
             stage = (y, d_idx)
             grid = self._get_possible_periods(estimate, run)
             errors = yield FitRequest(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, True)
@@ -580,7 +589,18 @@ class PARRM:
 
     def _get_filter_half_width(self) -> int:
         """Smallest half-width covering 50 in-phase offsets beyond the omitted centre, capped at
-        (N-1)//2 (parrm.py:788-801; the `>= period + half-width` clause there never fires)."""
+        (N-1)//2 (parrm.py:788-801; the `>= period + half-width` clause there never fires).  A pure function of
+        (limit, omitted samples, period, period half-width): remembered (the reference's explorer, and any loop
+        over recordings of one study, asks the same question again and again)."""
+        key = ((self._n_samples - 1) // 2, self._omit_n_samples, float(self._period), float(self._period_half_width))
+        hit = _HALF_WIDTH_MEMO.get(key)
+        if hit is None:
+            if len(_HALF_WIDTH_MEMO) > 256:
+                _HALF_WIDTH_MEMO.clear()
+            hit = _HALF_WIDTH_MEMO[key] = self._walk_filter_half_width()
+        return hit
+
+    def _walk_filter_half_width(self) -> int:
         limit = (self._n_samples - 1) // 2
         width, hits = self._omit_n_samples, 0
         # the reference walks one offset at a time; the same walk in vectorised chunks
@@ -601,6 +621,13 @@ class PARRM:
         """Dense filter array (parrm.py:803-833): 1 at the centre, -1/S on every offset whose
         phase is within ``period_half_width`` of the centre's, 0 elsewhere."""
         hw, period, phw = self._filter_half_width, self._period, self._period_half_width
+        key = (hw, float(period), float(phw), self._omit_n_samples, self._filter_direction)
+        master = _FILTER_MEMO.get(key)
+        if master is not None:  # (same design as before: a fresh copy -- `filter` hands out the internal array)
+            self._filter = master.copy()
+            self._plans = {}
+            self._last_plan = None
+            return
         offsets = np.arange(-hw, hw + 1)
         phase = np.mod(offsets, period)
         chosen = ((phase <= phw) | (phase >= period - phw)) & (np.abs(offsets) > self._omit_n_samples)
@@ -619,6 +646,9 @@ class PARRM:
         taps[chosen] = 1.0
         taps = -taps / np.max((taps.sum(), np.finfo(np.float64).eps))
         taps[hw] = 1
+        if len(_FILTER_MEMO) > 64:
+            _FILTER_MEMO.clear()
+        _FILTER_MEMO[key] = taps.copy()
         self._filter = taps
         self._plans = {}  # device tables are rebuilt lazily for the new taps
         self._last_plan = None
