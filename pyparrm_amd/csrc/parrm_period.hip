@@ -308,10 +308,18 @@ typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 // NW = waves per workgroup: 4 (256 data columns; the Gram row-tiles spread over waves 0-2), or 1 for
 // recordings of <= 64 channels (one wave takes the 64 data columns and all nine Gram tiles: 21 MFMAs
 // per step instead of 60 -- few-channel recordings are the common case in practice).
-template <int NW, int CT>
+//
+// GM = 2, the "special rows" form of W'W (round 3): with W = [1, sin(k a), cos(k a)] every entry of W'W is a sum of
+// two of the moments C_m = sum_j cos(m a_j), S_m = sum_j sin(m a_j), m = 0 ... 2 bw (product-to-sum), and all of
+// those follow from THREE rows of the matrix: row 0 (m <= bw) and the rows of sin(bw a), cos(bw a)
+// (sin((bw+i) a) = sin(bw a) cos(i a) + cos(bw a) sin(i a), ...).  So a workgroup multiplies one 16-row tile -- the
+// three rows of each of its candidates, fetched by a fourth design-matrix load with per-lane row offsets -- with the
+// 48 stacked columns: 3 MFMAs per step instead of 9 (per wave 13 instead of 15 at 256 channels, 6 instead of 12 at
+// <= 16), and the solvers rebuild the matrix (gram_from_special_rows).  `kreal` = K = 2 bw + 1 (GM = 2 only).
+template <int NW, int CT, int GM = 1>
 __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy, const double *Ws, int n_pad, int n_idx,
                                                     int n_chans, int n_periods, int kpc, int nsplit, double *part,
-                                                    const Blk blk) {
+                                                    const Blk blk, int kreal = 0) {
     static_assert(NW == 1 || NW == 2 || NW == 4, "one wave (<= 64 channels), two (<= 128) or four (256 per block)");
     static_assert(CT == 4 || ((CT == 1 || CT == 2) && NW == 1), "CT = 1, 2: one-wave forms for <= 16 / <= 32 channels");
     // Gram row-tiles per wave: NW = 4: waves 0-2 one each (wave 3 repeats tile 2, not stored); NW = 2: wave 0 tiles
@@ -340,8 +348,16 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     const unsigned step_y = static_cast<unsigned>(4 * ldy * 8), step_w = 4 * KS * 8;
     unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
     unsigned vw = static_cast<unsigned>(((u_lo * 4 + sj) * KS + c) * 8);
+    // GM = 2: lane c of a sample group fetches special row c % 3 (rows 0, K-2, K-1) of candidate c / 3 of the stack
+    constexpr int NS = GM == 2 ? NG : 0;  // column tiles of the special-row product per wave (as Gram row tiles before)
+    unsigned vs = 0;
+    if constexpr (GM == 2) {
+        const int q = c / 3, t = c - 3 * q;
+        const int sp = q < ncb ? q * kpc + (t == 0 ? 0 : kreal - 3 + t) : 0;
+        vs = static_cast<unsigned>(((u_lo * 4 + sj) * KS + sp) * 8);
+    }
 
-    d4_t acc[3][CT], gacc[NG][3];
+    d4_t acc[3][CT], gacc[GM == 2 ? 1 : NG][3], gsp[NS == 0 ? 1 : NS];
     double yy[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) yy[t] = 0.0;
@@ -353,8 +369,10 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
 #pragma unroll
     for (int gr = 0; gr < NG; ++gr)
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) gacc[gr][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
-    double ra[D][3], ry[D][CT];
+        for (int ct = 0; ct < 3; ++ct) gacc[GM == 2 ? 0 : gr][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < (NS == 0 ? 1 : NS); ++k) gsp[k] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double ra[D][3], ry[D][CT], rs[D];
     auto fetch = [&](int d) {
         if constexpr (CT == 4) {
             const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
@@ -373,6 +391,10 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt)
             ra[d][rt] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw + rt * 128, 0, 0));
+        if constexpr (GM == 2) {
+            rs[d] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vs, 0, 0));
+            vs += step_w;
+        }
         if (col_ok) vy += step_y;
         vw += step_w;
     };
@@ -386,6 +408,7 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             for (int rt = 0; rt < 3; ++rt) a[rt] = ra[d][rt];
 #pragma unroll
             for (int t = 0; t < CT; ++t) y[t] = ry[d][t];
+            const double asp = GM == 2 ? rs[d] : 0.0;
             fetch(d);  // step u + d + D (past the end of the data: zeros)
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
@@ -394,7 +417,21 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
                 for (int rt = 0; rt < 3; ++rt)
                     acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
             }
-            if constexpr (NW == 4) {
+            if constexpr (GM == 2) {
+                // special rows x the wave's column tiles (NW = 4: tile min(wave, 2); NW = 2: wave 0 tiles 0 and 1,
+                // wave 1 tile 2 twice; NW = 1: all three) -- straight-line code, as for the full matrix below
+                if constexpr (NW == 4) {
+                    const double bw_ = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
+                    gsp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, bw_, gsp[0], 0, 0, 0);
+                } else if constexpr (NW == 2) {
+                    const double b0 = wv == 0 ? a[0] : a[2], b1 = wv == 0 ? a[1] : a[2];
+                    gsp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, b0, gsp[0], 0, 0, 0);
+                    gsp[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, b1, gsp[1], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) gsp[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, a[ct], gsp[ct], 0, 0, 0);
+                }
+            } else if constexpr (NW == 4) {
                 // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
                 // compiler shuttle the Gram accumulators between register files every step)
                 const double aw = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
@@ -439,7 +476,25 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             for (int t = 0; t < CT; ++t) row[col0 + t] = acc[rt][t][v];
         }
     }
-    if (wv < 3) {
+    if (GM == 2 && wv < 3) {
+        // D[special sj + 4v][stacked column 16*ct + c]: kept where the column belongs to the special row's candidate,
+        // in the cell the full matrix has for it (rows 0, K-2, K-1 of the candidate's W'W)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (NW == 2 && wv == 1 && k == 1) continue;  // (the repeated tile)
+            const int ct = NW == 4 ? wv : (NW == 2 ? (wv == 0 ? k : 2) : k);
+            const int col = 16 * ct + c;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = sj + 4 * v, q = i / 3, t = i - 3 * q;
+                const int pc = pb * ncb + q;
+                if (q >= ncb || col / kpc != q || pc >= n_periods) continue;
+                const int row = t == 0 ? 0 : kreal - 3 + t;
+                block_of(pc)[static_cast<int64_t>(row) * kNCol + kYCols + col] = gsp[k][v];
+            }
+        }
+    }
+    if (GM == 1 && wv < 3) {
 #pragma unroll
         for (int gr = 0; gr < NG; ++gr) {
             if (NW == 2 && wv == 1 && gr == 1) continue;  // (the repeated tile)
@@ -465,22 +520,27 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         }
     }
 }
-template <int NW, int CT = 4>
+template <int NW, int CT = 4, int GM = 1>
 __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, int64_t ldy, const double *Ws,
                                                               int n_pad, int n_idx, int n_chans, int n_periods,
-                                                              int kpc, int nsplit, double *part) {
-    fit_accum_mfma_body<NW, CT>(Y, ldy, Ws, n_pad, n_idx, n_chans, n_periods, kpc, nsplit, part, this_block());
+                                                              int kpc, int nsplit, double *part, int kreal) {
+    fit_accum_mfma_body<NW, CT, GM>(Y, ldy, Ws, n_pad, n_idx, n_chans, n_periods, kpc, nsplit, part, this_block(), kreal);
 }
 
 // red[(p*nz+zb)][e] = sum_s part[(p*nz+zb)][s][e], s ascending (deterministic)
 // (data columns beyond the recording's channels are never read by the solvers: skipped)
+// (ksp = K when the Gram kernel left only rows 0, K-2, K-1 of W'W -- its GM = 2 form --, else 0)
 __device__ __forceinline__ void fit_reduce_body(const double *part, int nsplit, int64_t elems, int nz, int n_chans,
-                                                double *red, const Blk blk) {
+                                                double *red, const Blk blk, int ksp) {
     const int64_t e = static_cast<int64_t>(blk.x) * blockDim.x + threadIdx.x;
     if (e >= elems) return;
     const int64_t pz = blk.y;
     const int col = static_cast<int>(e % kNCol), zb = static_cast<int>(pz % nz);
     if (col < kYCols && zb * kYCols + col >= n_chans) return;
+    if (ksp > 0 && col >= kYCols) {
+        const int row = static_cast<int>(e / kNCol);
+        if (row != 0 && row != ksp - 2 && row != ksp - 1) return;
+    }
     const double *src = part + pz * nsplit * elems + e;
     // the loads of eight slices are in flight together (a plain loop waited for each in turn: 18 us per
     // optimiser batch at 56 slices); the sum is still taken in slice order
@@ -497,8 +557,8 @@ __device__ __forceinline__ void fit_reduce_body(const double *part, int nsplit, 
     red[pz * elems + e] = a;
 }
 __global__ void __launch_bounds__(256) fit_reduce_kernel(const double *part, int nsplit, int64_t elems, int nz,
-                                                          int n_chans, double *red) {
-    fit_reduce_body(part, nsplit, elems, nz, n_chans, red, this_block());
+                                                          int n_chans, double *red, int ksp) {
+    fit_reduce_body(part, nsplit, elems, nz, n_chans, red, this_block(), ksp);
 }
 
 // One workgroup per candidate period: LU(G) with partial pivoting, solve for every channel,
@@ -653,9 +713,65 @@ __device__ inline unsigned long long dpp_max_u64(unsigned long long v) {
 // substitution phase is LDS-bound: 840 broadcast reads per wave).  It leaves its wave sum in a spare cell of the
 // candidate's block (row KP, columns kYCols + quarter: the y'y row has no Gram part) and fit_finish_kernel adds
 // the quarters in the order the NW = 4 form adds its waves: same bits, 58 -> 35 us per K = 41 batch.
+//
+// `special` != 0: the block holds rows 0, K-2 and K-1 of W'W only (the Gram kernel's GM = 2 form) and the matrix is
+// rebuilt from the moments C_m = sum cos(m a), S_m = sum sin(m a), m = 0 ... 2 bw, which those rows determine:
+//   m <= bw:  S_m = G[0][2m-1], C_m = G[0][2m]  (C_0 = G[0][0] = n);
+//   m = bw+i: S_m = G[sin_bw][cos_i] + G[cos_bw][sin_i],  C_m = G[cos_bw][cos_i] - G[sin_bw][sin_i];
+//   G[sin_k][sin_l] = (C_|k-l| - C_k+l)/2,  G[cos_k][cos_l] = (C_|k-l| + C_k+l)/2,  G[sin_k][cos_l] = (S_k+l + S_k-l)/2
+// (S_-m = -S_m).  Rows are ordered 1, sin(a), cos(a), sin(2a), ... (fit_trig_stacked_body).
+template <int K, int NT>
+__device__ __forceinline__ void gram_from_special_rows(const double *base, int goff, double *A, int KS, int tid) {
+    constexpr int BW = (K - 1) / 2;
+    __shared__ double rows3[3][K + 1];
+    __shared__ double Cm[2 * BW + 1], Sm[2 * BW + 1];
+    for (int e = tid; e < 3 * K; e += NT) {
+        const int t = e / K, c = e - t * K;
+        rows3[t][c] = base[static_cast<int64_t>(t == 0 ? 0 : K - 3 + t) * kNCol + kYCols + goff + c];
+    }
+    __syncthreads();
+    for (int m = tid; m <= 2 * BW; m += NT) {
+        double sm, cm;
+        if (m == 0) {
+            sm = 0.0;
+            cm = rows3[0][0];
+        } else if (m <= BW) {
+            sm = rows3[0][2 * m - 1];
+            cm = rows3[0][2 * m];
+        } else {
+            const int i = m - BW;
+            sm = rows3[1][2 * i] + rows3[2][2 * i - 1];
+            cm = rows3[2][2 * i] - rows3[1][2 * i - 1];
+        }
+        Sm[m] = sm;
+        Cm[m] = cm;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += NT) {
+        const int r = e / K, c = e - r * K;
+        double v;
+        if (r == 0 || c == 0) {
+            v = rows3[0][r + c];
+        } else {
+            const int k = (r + 1) >> 1, l = (c + 1) >> 1;  // harmonics; odd index = sine row
+            const bool rs = r & 1, cs = c & 1;
+            const int d = k > l ? k - l : l - k;
+            if (rs == cs) {
+                v = rs ? 0.5 * (Cm[d] - Cm[k + l]) : 0.5 * (Cm[d] + Cm[k + l]);
+            } else {
+                // sin(x) cos(y) = (sin(x + y) + sin(x - y)) / 2, x the sine's harmonic
+                const int x = rs ? k : l, y = rs ? l : k;
+                const double sd = x >= y ? Sm[x - y] : -Sm[y - x];
+                v = 0.5 * (Sm[k + l] + sd);
+            }
+        }
+        A[r * KS + c] = v;
+    }
+}
+
 template <int K, int NW>
 __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx, int n_chans, int KP, int nz, double lambda,
-                                                    double *err, const Blk blk) {
+                                                    double *err, const Blk blk, int special) {
     constexpr int KS = 49;  // odd row stride: lanes-as-rows accesses in the LU stay bank-conflict free
     constexpr int KE = (K + 2) & ~1;  // even row stride of the substitution copy: 16-byte aligned rows
     __shared__ double A[K * KS];    // Gram matrix in, read one row per lane by the LU
@@ -671,9 +787,13 @@ __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx
     const int quarter = NW == 4 ? (tid >> 6) : static_cast<int>(blk.y & 3);  // 64-channel quarter of a block
     const int ch = quarter * 64 + lane;                                             // channel within the block
 
-    for (int e = tid; e < K * K; e += 64 * NW) {
-        const int r = e / K, c = e % K;
-        A[r * KS + c] = base[r * kNCol + kYCols + goff + c];
+    if (special) {
+        gram_from_special_rows<K, 64 * NW>(base, goff, A, KS, tid);
+    } else {
+        for (int e = tid; e < K * K; e += 64 * NW) {
+            const int r = e / K, c = e % K;
+            A[r * KS + c] = base[r * kNCol + kYCols + goff + c];
+        }
     }
     if (tid < 64) perm[tid] = tid;
     if (tid == 0) singular = 0;
@@ -689,6 +809,11 @@ __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx
         double arow[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) arow[j] = lane < K ? A[lane * KS + j] : 0.0;
+        // Singular = LAPACK's exact zero pivot.  A matrix rebuilt from its moments carries ~4 eps n of rounding per
+        // entry where the full product has exact duplicates (a period so long that every cosine rounds to 1: columns
+        // that are EQUAL in W'W differ in the last bits here), so there a pivot within that noise of zero -- below
+        // 1e-12 n, n = G[0][0]; the pivots of a sound system are ~n/2 -- counts as the zero it stands for.
+        const double tiny = special ? 1e-12 * fabs(A[0]) : 0.0;
         bool done = lane >= K;
         int rank = -1;
         bool sing = false;
@@ -719,7 +844,7 @@ __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx
                 const int hi = __builtin_amdgcn_readlane(static_cast<int>(bits >> 32), pl);
                 prow[j] = __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
             }
-            if (prow[col] == 0.0) {  // exactly singular: numpy raises LinAlgError -> inf (parrm.py:627-628)
+            if (fabs(prow[col]) <= tiny) {  // singular: numpy raises LinAlgError -> inf (parrm.py:627-628)
                 sing = true;
                 break;
             }
@@ -825,8 +950,8 @@ __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx
 }
 template <int K, int NW>
 __global__ void __launch_bounds__(64 * NW) fit_solve_fast_kernel(const double *red, int n_idx, int n_chans, int KP,
-                                                                   int nz, double lambda, double *err) {
-    fit_solve_fast_body<K, NW>(red, n_idx, n_chans, KP, nz, lambda, err, this_block());
+                                                                   int nz, double lambda, double *err, int special) {
+    fit_solve_fast_body<K, NW>(red, n_idx, n_chans, KP, nz, lambda, err, this_block(), special);
 }
 
 // the channel mean of the NW = 1 form: quarters added as the NW = 4 form adds its waves, blocks in order; then, for
@@ -878,26 +1003,27 @@ __global__ void __launch_bounds__(256) fit_trig_stacked_gang(const GangProblem *
                           Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
 }
 
-template <int NW, int CT = 4>
-__global__ void __launch_bounds__(256) fit_accum_mfma_gang(const GangProblem *tab, int kpc) {
+template <int NW, int CT = 4, int GM = 1>
+__global__ void __launch_bounds__(256) fit_accum_mfma_gang(const GangProblem *tab, int kpc, int kreal) {
     const GangProblem &q = tab[blockIdx.z];
     if (static_cast<int>(blockIdx.x) >= q.nsplit || static_cast<int>(blockIdx.y) >= q.groups) return;
-    fit_accum_mfma_body<NW, CT>(q.y, q.ldy, q.wmat, q.n_pad, q.n_idx, q.n_chans, q.n_periods, kpc, q.nsplit, q.part,
-                            Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+    fit_accum_mfma_body<NW, CT, GM>(q.y, q.ldy, q.wmat, q.n_pad, q.n_idx, q.n_chans, q.n_periods, kpc, q.nsplit, q.part,
+                                    Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1}, kreal);
 }
 
-__global__ void __launch_bounds__(256) fit_reduce_gang(const GangProblem *tab, int64_t elems) {
+__global__ void __launch_bounds__(256) fit_reduce_gang(const GangProblem *tab, int64_t elems, int ksp) {
     const GangProblem &q = tab[blockIdx.z];
     if (q.nsplit == 1 || static_cast<int>(blockIdx.y) >= q.n_periods) return;
-    fit_reduce_body(q.part, q.nsplit, elems, 1, q.n_chans, q.red, Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+    fit_reduce_body(q.part, q.nsplit, elems, 1, q.n_chans, q.red,
+                    Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1}, ksp);
 }
 
 template <int K, int NW>
-__global__ void __launch_bounds__(64 * NW) fit_solve_fast_gang(const GangProblem *tab, int KP) {
+__global__ void __launch_bounds__(64 * NW) fit_solve_fast_gang(const GangProblem *tab, int KP, int special) {
     const GangProblem &q = tab[blockIdx.z];
     if (static_cast<int>(blockIdx.x) >= q.n_periods) return;
     fit_solve_fast_body<K, NW>(q.red, q.n_idx, q.n_chans, KP, 1, q.lambda, q.err,
-                               Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+                               Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1}, special);
 }
 
 // one workgroup for the whole call: quarter sums -> errors where the one-wave solve ran (K = 41), every problem's
@@ -1222,31 +1348,41 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
     PARRM_HIP_CHECK(hipGetLastError());
     const dim3 grid(g.nsplit, groups, g.nz);
     const bool narrow_ok = !getenv("PARRM_FIT_NO_NARROW16");  // (A/B knob: the 64-column form for every C <= 64)
+    const int K = 2 * bw + 1;
+    // W'W from three of its rows (GM = 2 of fit_accum_mfma_body) where the fast solvers rebuild it; the reference's
+    // operation order (sincos of the rounded k*a per harmonic) breaks the angle-addition identities at the 1e-10 of
+    // its argument rounding, so that mode keeps the full matrix.  PARRM_FIT_FULL_GRAM=1: the full matrix always.
+    const bool special = use_mfma && (K == 11 || K == 21 || K == 41) && !exact_trig && !getenv("PARRM_FIT_FULL_GRAM");
+#define PARRM_LAUNCH_ACCUM(NW_, CT_, THREADS_)                                                                              \
+    do {                                                                                                                   \
+        if (special)                                                                                                       \
+            hipLaunchKernelGGL((fit_accum_mfma_kernel<NW_, CT_, 2>), grid, dim3(THREADS_), 0, s, d_y, ldy, wmat, g.n_pad, n, C, \
+                               P, g.KP, g.nsplit, part, K);                                                                \
+        else                                                                                                               \
+            hipLaunchKernelGGL((fit_accum_mfma_kernel<NW_, CT_, 1>), grid, dim3(THREADS_), 0, s, d_y, ldy, wmat, g.n_pad, n, C, \
+                               P, g.KP, g.nsplit, part, K);                                                                \
+    } while (0)
     if (use_mfma && C <= 16 && narrow_ok)
-        hipLaunchKernelGGL((fit_accum_mfma_kernel<1, 1>), grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
-                           part);
+        PARRM_LAUNCH_ACCUM(1, 1, 64);
     else if (use_mfma && C <= 32 && narrow_ok)
-        hipLaunchKernelGGL((fit_accum_mfma_kernel<1, 2>), grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
-                           part);
+        PARRM_LAUNCH_ACCUM(1, 2, 64);
     else if (use_mfma && C <= 64)
-        hipLaunchKernelGGL(fit_accum_mfma_kernel<1>, grid, dim3(64), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
-                           part);
+        PARRM_LAUNCH_ACCUM(1, 4, 64);
     else if (use_mfma && C <= 128 && g.nz == 1 && !getenv("PARRM_FIT_NO_TWO_WAVES"))
-        hipLaunchKernelGGL(fit_accum_mfma_kernel<2>, grid, dim3(128), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
-                           part);
+        PARRM_LAUNCH_ACCUM(2, 4, 128);
     else if (use_mfma)
-        hipLaunchKernelGGL(fit_accum_mfma_kernel<4>, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit,
-                           part);
+        PARRM_LAUNCH_ACCUM(4, 4, 256);
     else
         hipLaunchKernelGGL(fit_accum_kernel, grid, dim3(256), 0, s, d_y, ldy, wmat, g.n_pad, n, C, P, g.KP, g.nsplit, part);
+#undef PARRM_LAUNCH_ACCUM
     PARRM_HIP_CHECK(hipGetLastError());
     if (g.nsplit > 1) {
         const dim3 rgrid(static_cast<unsigned>((g.elems + 255) / 256), static_cast<unsigned>(n_periods * g.nz));
         PARRM_REQUIRE(n_periods * g.nz <= 65535, "fit_errors: periods x column blocks too large");
-        hipLaunchKernelGGL(fit_reduce_kernel, rgrid, dim3(256), 0, s, part, g.nsplit, g.elems, g.nz, C, red);
+        hipLaunchKernelGGL(fit_reduce_kernel, rgrid, dim3(256), 0, s, part, g.nsplit, g.elems, g.nz, C, red, special ? K : 0);
         PARRM_HIP_CHECK(hipGetLastError());
     }
-    const int K = 2 * bw + 1;
+    const int sp = special ? 1 : 0;
     if (K == 11 || K == 21 || K == 41) {
         // small batches (the optimiser's steps): one wave per 64-channel quarter, see fit_solve_fast_kernel
         // (measured per batch, 256 channels: K = 41 222 -> 208 us at 9 candidates, 155 -> 141 us at 4; K = 21 and 11
@@ -1255,11 +1391,11 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
         if (quarters) {
             const dim3 sg(static_cast<unsigned>(n_periods), static_cast<unsigned>(4 * g.nz)), sb(64);
             if (K == 11)
-                hipLaunchKernelGGL((fit_solve_fast_kernel<11, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+                hipLaunchKernelGGL((fit_solve_fast_kernel<11, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err, sp);
             else if (K == 21)
-                hipLaunchKernelGGL((fit_solve_fast_kernel<21, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+                hipLaunchKernelGGL((fit_solve_fast_kernel<21, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err, sp);
             else
-                hipLaunchKernelGGL((fit_solve_fast_kernel<41, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+                hipLaunchKernelGGL((fit_solve_fast_kernel<41, 1>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err, sp);
             PARRM_HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(fit_finish_kernel, dim3(1), dim3(64), 0, s, red, P, g.KP, g.nz, C, d_err,
                                pub ? pub->host_err : nullptr, pub ? pub->flag : nullptr, pub ? pub->seq : 0ull);
@@ -1269,11 +1405,11 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
         }
         const dim3 sg(static_cast<unsigned>(n_periods)), sb(256);
         if (K == 11)
-            hipLaunchKernelGGL((fit_solve_fast_kernel<11, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            hipLaunchKernelGGL((fit_solve_fast_kernel<11, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err, sp);
         else if (K == 21)
-            hipLaunchKernelGGL((fit_solve_fast_kernel<21, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            hipLaunchKernelGGL((fit_solve_fast_kernel<21, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err, sp);
         else
-            hipLaunchKernelGGL((fit_solve_fast_kernel<41, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err);
+            hipLaunchKernelGGL((fit_solve_fast_kernel<41, 4>), sg, sb, 0, s, red, n, C, g.KP, g.nz, lambda, d_err, sp);
         PARRM_HIP_CHECK(hipGetLastError());
         return PARRM_OK;
     }
@@ -1453,25 +1589,37 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         const unsigned nz = static_cast<unsigned>(hi - lo);
         const GangProblem *sub = d_tab + lo;
         hipLaunchKernelGGL(fit_trig_stacked_gang, dim3(max_trig, max_groups, nz), dim3(64 * ncb), 0, s, sub, bw, KP, exact);
+        const bool special = !exact && !getenv("PARRM_FIT_FULL_GRAM");  // (see fit_errors_impl)
+        const dim3 agrid(max_split, max_groups, nz);
+#define PARRM_LAUNCH_GANG(NW_, CT_, THREADS_)                                                                           \
+    do {                                                                                                               \
+        if (special)                                                                                                   \
+            hipLaunchKernelGGL((fit_accum_mfma_gang<NW_, CT_, 2>), agrid, dim3(THREADS_), 0, s, sub, KP, K);             \
+        else                                                                                                           \
+            hipLaunchKernelGGL((fit_accum_mfma_gang<NW_, CT_, 1>), agrid, dim3(THREADS_), 0, s, sub, KP, K);             \
+    } while (0)
         if (width == 0)
-            hipLaunchKernelGGL((fit_accum_mfma_gang<1, 1>), dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
+            PARRM_LAUNCH_GANG(1, 1, 64);
         else if (width == 3)
-            hipLaunchKernelGGL((fit_accum_mfma_gang<1, 2>), dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
+            PARRM_LAUNCH_GANG(1, 2, 64);
         else if (width == 1)
-            hipLaunchKernelGGL(fit_accum_mfma_gang<1>, dim3(max_split, max_groups, nz), dim3(64), 0, s, sub, KP);
+            PARRM_LAUNCH_GANG(1, 4, 64);
         else
-            hipLaunchKernelGGL(fit_accum_mfma_gang<4>, dim3(max_split, max_groups, nz), dim3(256), 0, s, sub, KP);
+            PARRM_LAUNCH_GANG(4, 4, 256);
+#undef PARRM_LAUNCH_GANG
         const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
+        const int sp = special ? 1 : 0;
         if (any_split)
-            hipLaunchKernelGGL(fit_reduce_gang, dim3(static_cast<unsigned>((elems + 255) / 256), max_p, nz), dim3(256), 0, s, sub, elems);
+            hipLaunchKernelGGL(fit_reduce_gang, dim3(static_cast<unsigned>((elems + 255) / 256), max_p, nz), dim3(256), 0, s, sub,
+                               elems, special ? K : 0);
         if (K == 11)
-            hipLaunchKernelGGL((fit_solve_fast_gang<11, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP);
+            hipLaunchKernelGGL((fit_solve_fast_gang<11, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP, sp);
         else if (K == 21)
-            hipLaunchKernelGGL((fit_solve_fast_gang<21, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP);
+            hipLaunchKernelGGL((fit_solve_fast_gang<21, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP, sp);
         else if (quarters[lo] > 0)
-            hipLaunchKernelGGL((fit_solve_fast_gang<41, 1>), dim3(max_p, 4, nz), dim3(64), 0, s, sub, KP);
+            hipLaunchKernelGGL((fit_solve_fast_gang<41, 1>), dim3(max_p, 4, nz), dim3(64), 0, s, sub, KP, sp);
         else
-            hipLaunchKernelGGL((fit_solve_fast_gang<41, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP);
+            hipLaunchKernelGGL((fit_solve_fast_gang<41, 4>), dim3(max_p, 1, nz), dim3(256), 0, s, sub, KP, sp);
         PARRM_HIP_CHECK(hipGetLastError());
         lo = hi;
     }
