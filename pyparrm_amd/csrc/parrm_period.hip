@@ -185,6 +185,57 @@ __global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const int64_t *id
     fit_trig_stacked_body(idx, n_idx, n_pad, periods, n_periods, bw, kpc, exact, Ws, this_block());
 }
 
+// The PACKED stacked layout (GM = 2 of fit_accum_mfma_body): global row K p + k for row k of candidate p, stack
+// s = global rows [48 s, 48 s + 48).  One workgroup = 64 samples x one stack; wave q = the q-th candidate with rows in
+// the stack (<= 6 / 4 / 3 of them at K = 11 / 21 / 41: a candidate that straddles two stacks is evaluated by both
+// workgroups -- the recurrence is cheap beside the 24 KB the workgroup writes, and the block leaves as ONE contiguous
+// run as in the padded layout; writing per candidate group instead, <= 2 runs of 41-44 rows per sample, measured
+// twice the time: partial lines shared with the neighbouring group).  Candidates >= n_periods and samples >= n_idx
+// are zeros.
+constexpr int packed_trig_waves(int K) { return (48 + K - 2) / K + 1; }  // most candidates a 48-row window can touch
+__device__ __forceinline__ void fit_trig_packed_body(const int64_t *idx, int n_idx, int n_pad, const double *periods,
+                                                     int n_periods, int bw, int exact, double *Ws, const Blk blk) {
+    constexpr int KS = 48, TS = 49;
+    __shared__ double tile[64 * TS];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int K = 2 * bw + 1;
+    const int g0 = KS * blk.y;       // first global row of the stack
+    const int p = g0 / K + q;        // this wave's candidate
+    const int k_lo = max(g0 - p * K, 0), k_hi = min(g0 + KS - p * K, K);  // its rows [k_lo, k_hi) lie in the stack
+    const int j = blk.x * 64 + lane;
+    if (k_lo < k_hi) {
+        double *t = tile + lane * TS + (p * K - g0);  // t[k] = row k of the candidate (k_lo <= k < k_hi)
+        if (j >= n_idx || p >= n_periods) {
+            for (int k = k_lo; k < k_hi; ++k) t[k] = 0.0;
+        } else {
+            const double w0 = 6.283185307179586 / periods[p];         // (2 * np.pi / period)
+            const double ang = static_cast<double>(idx[j] + 1) * w0;  // (indices + 1) * ...
+            if (k_lo == 0) t[0] = 1.0;
+            double s1, c1;
+            sincos(ang, &s1, &c1);
+            double sk = s1, ck = c1;
+            for (int k = 1; 2 * k - 1 < k_hi; ++k) {
+                if (exact && k > 1) sincos(static_cast<double>(k) * ang, &sk, &ck);
+                if (2 * k - 1 >= k_lo) t[2 * k - 1] = sk;
+                if (2 * k >= k_lo && 2 * k < k_hi) t[2 * k] = ck;
+                const double sn = fma(sk, c1, ck * s1);
+                const double cn = fma(ck, c1, -(sk * s1));
+                sk = sn;
+                ck = cn;
+            }
+        }
+    }
+    __syncthreads();
+    const int rows = min(64, n_pad - blk.x * 64);  // n_pad is a multiple of 16
+    double *dst = Ws + (static_cast<int64_t>(blk.y) * n_pad + static_cast<int64_t>(blk.x) * 64) * KS;
+    for (int e = threadIdx.x; e < rows * KS; e += blockDim.x) dst[e] = tile[(e / KS) * TS + (e % KS)];
+}
+__global__ void __launch_bounds__(384) fit_trig_packed_kernel(const int64_t *idx, int n_idx, int n_pad,
+                                                               const double *periods, int n_periods, int bw, int exact,
+                                                               double *Ws) {
+    fit_trig_packed_body(idx, n_idx, n_pad, periods, n_periods, bw, exact, Ws, this_block());
+}
+
 // ---- Gram blocks -----------------------------------------------------------------------------
 // One workgroup = 4 waves x 12 stacked design rows = NCB = 48/KPC candidates (KPC = 12/24/48 padded
 // rows per candidate), all data columns of one 256-channel block plus the 48 stacked W columns
@@ -309,13 +360,20 @@ typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 // recordings of <= 64 channels (one wave takes the 64 data columns and all nine Gram tiles: 21 MFMAs
 // per step instead of 60 -- few-channel recordings are the common case in practice).
 //
-// GM = 2, the "special rows" form of W'W (round 3): with W = [1, sin(k a), cos(k a)] every entry of W'W is a sum of
-// two of the moments C_m = sum_j cos(m a_j), S_m = sum_j sin(m a_j), m = 0 ... 2 bw (product-to-sum), and all of
-// those follow from THREE rows of the matrix: row 0 (m <= bw) and the rows of sin(bw a), cos(bw a)
-// (sin((bw+i) a) = sin(bw a) cos(i a) + cos(bw a) sin(i a), ...).  So a workgroup multiplies one 16-row tile -- the
-// three rows of each of its candidates, fetched by a fourth design-matrix load with per-lane row offsets -- with the
-// 48 stacked columns: 3 MFMAs per step instead of 9 (per wave 13 instead of 15 at 256 channels, 6 instead of 12 at
-// <= 16), and the solvers rebuild the matrix (gram_from_special_rows).  `kreal` = K = 2 bw + 1 (GM = 2 only).
+// GM = 2 (round 3): PACKED rows and the "special rows" form of W'W.
+//  * Packed: the design rows of the candidates follow each other without padding -- global row K p + k for row k of
+//    candidate p, stack s = global rows [48 s, 48 s + 48) -- so a candidate may straddle two stacks and no MFMA row is
+//    spent on padding (GM = 1 pads a candidate to kpc = 12 / 24 / 48 rows: 8 / 12.5 / 15 % of the products at
+//    K = 11 / 21 / 41).  An MFMA output row depends on its own A row only, so where a row sits changes no bit of it.
+//  * Special rows: with W = [1, sin(k a), cos(k a)] every entry of W'W is a sum of two of the moments
+//    C_m = sum_j cos(m a_j), S_m = sum_j sin(m a_j), m = 0 ... 2 bw (product-to-sum), and all of those follow from
+//    THREE rows of the matrix: row 0 (m <= bw) and the rows of sin(bw a), cos(bw a)
+//    (sin((bw+i) a) = sin(bw a) cos(i a) + cos(bw a) sin(i a), ...).  So per 16-column tile of the stack one extra
+//    A operand -- the three rows of each of the <= 3 candidates that own columns of the tile, fetched with per-lane
+//    row offsets (from the neighbouring stack where a candidate straddles) -- is multiplied with the tile: 3 MFMAs
+//    per workgroup and step instead of 9 (per wave 13 instead of 15 at 256 channels, 6 instead of 12 at <= 16), and
+//    the solvers rebuild the matrix (gram_from_special_rows).
+// `kreal` = K = 2 bw + 1 (GM = 2 only; kpc is then only the row count of a candidate's result block).
 template <int NW, int CT, int GM = 1>
 __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy, const double *Ws, int n_pad, int n_idx,
                                                     int n_chans, int n_periods, int kpc, int nsplit, double *part,
@@ -348,13 +406,30 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     const unsigned step_y = static_cast<unsigned>(4 * ldy * 8), step_w = 4 * KS * 8;
     unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
     unsigned vw = static_cast<unsigned>(((u_lo * 4 + sj) * KS + c) * 8);
-    // GM = 2: lane c of a sample group fetches special row c % 3 (rows 0, K-2, K-1) of candidate c / 3 of the stack
+    // GM = 2: per column tile of the wave, lane c of a sample group fetches special row c % 3 (rows 0, K-2, K-1) of the
+    // (c / 3)-th candidate that owns columns of the tile; the descriptor spans the stacks s-1 ... s+1
     constexpr int NS = GM == 2 ? NG : 0;  // column tiles of the special-row product per wave (as Gram row tiles before)
-    unsigned vs = 0;
+    const int K = kreal, g0 = KS * pb;    // (GM = 2) first global row of this stack
+    const int n_stacks = GM == 2 ? (n_periods * K + KS - 1) / KS : 0;
+    const int s_base = max(pb - 1, 0);
+    const __amdgpu_buffer_rsrc_t rs_sp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Ws) + static_cast<int64_t>(s_base) * n_pad * KS, 0,
+        GM == 2 ? min(3, n_stacks - s_base) * n_pad * KS * 8 : 0, 0x00020000);
+    auto tile_of = [&](int k) -> int {  // column tile k of this wave
+        return NW == 4 ? min(wv, 2) : (NW == 2 ? (wv == 0 ? k : 2) : k);
+    };
+    unsigned vs[NS == 0 ? 1 : NS];
     if constexpr (GM == 2) {
-        const int q = c / 3, t = c - 3 * q;
-        const int sp = q < ncb ? q * kpc + (t == 0 ? 0 : kreal - 3 + t) : 0;
-        vs = static_cast<unsigned>(((u_lo * 4 + sj) * KS + sp) * 8);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int gl = g0 + 16 * tile_of(k);  // first global row (= W'W column) of the tile
+            const int ci = c / 3, t = c - 3 * ci;
+            const int pc = gl / K + ci;
+            const bool own = pc <= (gl + 15) / K && pc < n_periods;
+            const int gsp = own ? pc * K + (t == 0 ? 0 : K - 3 + t) : gl;
+            const int s2 = gsp / KS, r2 = gsp - KS * s2;
+            vs[k] = static_cast<unsigned>(((static_cast<int64_t>(s2 - s_base) * n_pad + u_lo * 4 + sj) * KS + r2) * 8);
+        }
     }
 
     d4_t acc[3][CT], gacc[GM == 2 ? 1 : NG][3], gsp[NS == 0 ? 1 : NS];
@@ -372,7 +447,7 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         for (int ct = 0; ct < 3; ++ct) gacc[GM == 2 ? 0 : gr][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < (NS == 0 ? 1 : NS); ++k) gsp[k] = d4_t{0.0, 0.0, 0.0, 0.0};
-    double ra[D][3], ry[D][CT], rs[D];
+    double ra[D][3], ry[D][CT], rs[D][NS == 0 ? 1 : NS];
     auto fetch = [&](int d) {
         if constexpr (CT == 4) {
             const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
@@ -392,8 +467,11 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         for (int rt = 0; rt < 3; ++rt)
             ra[d][rt] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw + rt * 128, 0, 0));
         if constexpr (GM == 2) {
-            rs[d] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vs, 0, 0));
-            vs += step_w;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                rs[d][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_sp, vs[k], 0, 0));
+                vs[k] += step_w;
+            }
         }
         if (col_ok) vy += step_y;
         vw += step_w;
@@ -408,7 +486,9 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             for (int rt = 0; rt < 3; ++rt) a[rt] = ra[d][rt];
 #pragma unroll
             for (int t = 0; t < CT; ++t) y[t] = ry[d][t];
-            const double asp = GM == 2 ? rs[d] : 0.0;
+            double asp[NS == 0 ? 1 : NS];
+#pragma unroll
+            for (int k = 0; k < (NS == 0 ? 1 : NS); ++k) asp[k] = GM == 2 ? rs[d][k] : 0.0;
             fetch(d);  // step u + d + D (past the end of the data: zeros)
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
@@ -422,14 +502,15 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
                 // wave 1 tile 2 twice; NW = 1: all three) -- straight-line code, as for the full matrix below
                 if constexpr (NW == 4) {
                     const double bw_ = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
-                    gsp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, bw_, gsp[0], 0, 0, 0);
+                    gsp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp[0], bw_, gsp[0], 0, 0, 0);
                 } else if constexpr (NW == 2) {
                     const double b0 = wv == 0 ? a[0] : a[2], b1 = wv == 0 ? a[1] : a[2];
-                    gsp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, b0, gsp[0], 0, 0, 0);
-                    gsp[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, b1, gsp[1], 0, 0, 0);
+                    gsp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp[0], b0, gsp[0], 0, 0, 0);
+                    gsp[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp[1], b1, gsp[1], 0, 0, 0);
                 } else {
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) gsp[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, a[ct], gsp[ct], 0, 0, 0);
+                    for (int ct = 0; ct < 3; ++ct)
+                        gsp[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(asp[ct], a[ct], gsp[ct], 0, 0, 0);
                 }
             } else if constexpr (NW == 4) {
                 // W'W row-tile min(wave, 2): straight-line (a wave-uniform branch here made the
@@ -469,28 +550,30 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int r = 16 * rt + sj + 4 * v;
-            const int pc = pb * ncb + r / kpc;
+            // candidate and row within it: GM = 2 packed (global row g0 + r = K pc + k), GM = 1 padded to kpc rows
+            const int pc = GM == 2 ? (g0 + r) / K : pb * ncb + r / kpc;
+            const int k = GM == 2 ? g0 + r - pc * K : r % kpc;
             if (pc >= n_periods) continue;
-            double *row = block_of(pc) + static_cast<int64_t>(r % kpc) * kNCol;
+            double *row = block_of(pc) + static_cast<int64_t>(k) * kNCol;
 #pragma unroll
             for (int t = 0; t < CT; ++t) row[col0 + t] = acc[rt][t][v];
         }
     }
     if (GM == 2 && wv < 3) {
-        // D[special sj + 4v][stacked column 16*ct + c]: kept where the column belongs to the special row's candidate,
-        // in the cell the full matrix has for it (rows 0, K-2, K-1 of the candidate's W'W)
+        // D[special sj + 4v][column 16*ct + c of the stack]: kept where the column belongs to the special row's
+        // candidate, in the cell the full matrix has for it (rows 0, K-2, K-1, column k of the candidate's W'W)
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (NW == 2 && wv == 1 && k == 1) continue;  // (the repeated tile)
-            const int ct = NW == 4 ? wv : (NW == 2 ? (wv == 0 ? k : 2) : k);
-            const int col = 16 * ct + c;
+        for (int kk = 0; kk < NS; ++kk) {
+            if (NW == 2 && wv == 1 && kk == 1) continue;  // (the repeated tile)
+            const int gl = g0 + 16 * tile_of(kk), g = gl + c;
+            const int pg = g / K, k = g - pg * K;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int i = sj + 4 * v, q = i / 3, t = i - 3 * q;
-                const int pc = pb * ncb + q;
-                if (q >= ncb || col / kpc != q || pc >= n_periods) continue;
-                const int row = t == 0 ? 0 : kreal - 3 + t;
-                block_of(pc)[static_cast<int64_t>(row) * kNCol + kYCols + col] = gsp[k][v];
+                const int i = sj + 4 * v, ci = i / 3, t = i - 3 * ci;
+                const int pc = gl / K + ci;
+                if (pc != pg || pc >= n_periods) continue;
+                const int row = t == 0 ? 0 : K - 3 + t;
+                block_of(pc)[static_cast<int64_t>(row) * kNCol + kYCols + k] = gsp[kk][v];
             }
         }
     }
@@ -511,8 +594,9 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         }
     }
     if (sj == 0) {
-        for (int q = 0; q < ncb; ++q) {
-            const int pc = pb * ncb + q;
+        // (GM = 2: every candidate with rows in this stack -- one that straddles gets the same sums from both)
+        const int p_lo = GM == 2 ? g0 / K : pb * ncb, p_hi = GM == 2 ? (g0 + KS - 1) / K : pb * ncb + ncb - 1;
+        for (int pc = p_lo; pc <= p_hi; ++pc) {
             if (pc >= n_periods) break;
             double *row = block_of(pc) + static_cast<int64_t>(kpc) * kNCol;
 #pragma unroll
@@ -815,7 +899,7 @@ __device__ __forceinline__ void fit_solve_fast_body(const double *red, int n_idx
     __shared__ double wsum[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int p = blk.x;
-    const int goff = (p % (48 / KP)) * KP;
+    const int goff = special ? 0 : (p % (48 / KP)) * KP;  // (the packed Gram form leaves column k at kYCols + k)
     const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
     const double *base = red + static_cast<int64_t>(p) * nz * elems;
     const int quarter = NW == 4 ? (tid >> 6) : static_cast<int>(blk.y & 3);  // 64-channel quarter of a block
@@ -1041,6 +1125,13 @@ __global__ void __launch_bounds__(256) fit_trig_stacked_gang(const GangProblem *
                           Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
 }
 
+__global__ void __launch_bounds__(384) fit_trig_packed_gang(const GangProblem *tab, int bw, int exact) {
+    const GangProblem &q = tab[blockIdx.z];
+    if (static_cast<int>(blockIdx.x) >= q.trig_blocks || static_cast<int>(blockIdx.y) >= q.groups) return;
+    fit_trig_packed_body(q.idx, q.n_idx, q.n_pad, q.periods, q.n_periods, bw, exact, q.wmat,
+                         Blk{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), 0, 1});
+}
+
 template <int NW, int CT = 4, int GM = 1>
 __global__ void __launch_bounds__(256) fit_accum_mfma_gang(const GangProblem *tab, int kpc, int kreal) {
     const GangProblem &q = tab[blockIdx.z];
@@ -1098,7 +1189,21 @@ struct FitGeom {
     size_t w_bytes;      // design matrices
     size_t part_bytes;   // all partial Gram blocks
     size_t red_bytes;    // reduced blocks (0 when nsplit == 1: part is used in place)
+    bool packed;         // candidates' design rows packed (fit_accum_mfma_body GM = 2), else padded to KP rows each
+    int groups;          // 48-row stacks of the design matrix in the planned layout
 };
+
+// The packed rows + special-rows Gram form (GM = 2) is taken where the fast solvers exist.  The reference's operation
+// order (sincos of the rounded k*a per harmonic) breaks the angle-addition identities at the 1e-10 of its argument
+// rounding, so that mode keeps the full product in the padded layout.  PARRM_FIT_FULL_GRAM=1: the padded form always.
+static int exact_trig_mode() {
+    static const int mode = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
+    return mode;
+}
+static bool packed_form(int bw) {
+    const int K = 2 * bw + 1;
+    return (K == 11 || K == 21 || K == 41) && !exact_trig_mode() && !getenv("PARRM_FIT_FULL_GRAM");
+}
 
 // `plan_periods` (>= n_periods): the candidate count the sample split is chosen for.  A slice of a
 // larger grid is planned as the whole grid would be, so that every candidate goes through exactly the
@@ -1110,8 +1215,14 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw, 
     g.nz = static_cast<int>((n_chans + kYCols - 1) / kYCols);
     g.n_pad = static_cast<int>((n_idx + kTJ - 1) / kTJ * kTJ);
     const int64_t tiles = g.n_pad / kTJ;
-    const int64_t groups = (n_periods + (48 / g.KP) - 1) / (48 / g.KP);  // workgroups per sample slice
-    const int64_t plan_groups = plan_periods > n_periods ? (plan_periods + (48 / g.KP) - 1) / (48 / g.KP) : groups;
+    g.packed = packed_form(bw);
+    const int64_t K = 2 * bw + 1;
+    auto stacks = [&](int64_t periods, bool packed) {
+        return packed ? (periods * K + 47) / 48 : (periods + (48 / g.KP) - 1) / (48 / g.KP);
+    };
+    const int64_t groups = stacks(n_periods, g.packed);  // workgroups per sample slice
+    const int64_t plan_groups = plan_periods > n_periods ? stacks(plan_periods, g.packed) : groups;
+    g.groups = static_cast<int>(groups);
     // Sample slices per candidate group.  512 workgroups are resident at once (2 per CU), so the run
     // time is ~ceil(workgroups / 512) rounds of (work per workgroup ~ 1/nsplit): pick the nsplit
     // that minimises rounds/nsplit (e.g. 381 candidates: nsplit 2 -> 762 workgroups = 2 rounds,
@@ -1130,7 +1241,8 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw, 
         }
     }
     g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
-    g.w_bytes = static_cast<size_t>(groups) * 48 * g.n_pad * sizeof(double);  // whole 48-row stacks
+    // whole 48-row stacks (room for the padded layout too: operands the matrix cores cannot take fall back to it)
+    g.w_bytes = static_cast<size_t>(std::max(groups, stacks(n_periods, false))) * 48 * g.n_pad * sizeof(double);
     g.part_bytes = static_cast<size_t>(n_periods) * g.nz * g.nsplit * g.elems * sizeof(double);
     g.red_bytes = g.nsplit > 1 ? static_cast<size_t>(n_periods) * g.nz * g.elems * sizeof(double) : 0;
     return g;
@@ -1323,10 +1435,6 @@ int parrm_fit_errors(const double *d_y, int64_t ldy, const int64_t *d_idx, int64
 
 // hand-off of an optimiser batch's errors to the host (parrm_fit_errors_host): when the batch takes the one-wave
 // solve, its finishing kernel publishes too and `done` is set
-static int exact_trig_mode() {
-    static const int mode = getenv("PARRM_FIT_EXACT_TRIG") ? atoi(getenv("PARRM_FIT_EXACT_TRIG")) : 0;
-    return mode;
-}
 
 struct Publish {
     double *host_err;
@@ -1369,28 +1477,29 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
     const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans), P = static_cast<int>(n_periods);
     const int exact_trig = exact_trig_mode();
     const int ncb = 48 / g.KP;
-    const int groups = (P + ncb - 1) / ncb;
     // matrix-core path: needs 16-byte aligned column quads (even ldy) and 31-bit byte offsets; else the
     // vector-ALU kernel
     const char *accum_env = getenv("PARRM_FIT_ACCUM");  // 1 = vector-ALU kernel (read per call: tests A/B the two)
     const int accum_choice = accum_env ? atoi(accum_env) : 0;
     const bool mfma_ok = ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 &&
-                         n_idx * ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(g.n_pad) * 48 * 8 < 0x7fff0000LL;
+                         n_idx * ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(g.n_pad) * 48 * 8 * 3 < 0x7fff0000LL;
     const bool use_mfma = accum_choice == 1 ? false : mfma_ok;
-    if (use_mfma)
+    const int K = 2 * bw + 1;
+    const bool special = use_mfma && g.packed;  // packed rows, W'W from three of its rows (fit_accum_mfma_body GM = 2)
+    const int groups = special ? g.groups : (P + ncb - 1) / ncb;
+    if (special) {
+        hipLaunchKernelGGL(fit_trig_packed_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * packed_trig_waves(K)), 0, s,
+                           d_idx, n, g.n_pad, d_periods, P, bw, exact_trig, wmat);
+    } else if (use_mfma) {
         hipLaunchKernelGGL(fit_trig_stacked_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * ncb), 0, s, d_idx, n,
                            g.n_pad, d_periods, P, bw, g.KP, exact_trig, wmat);
-    else
+    } else {
         hipLaunchKernelGGL(fit_trig_kernel, dim3((g.n_pad + 255) / 256, P), dim3(256), 0, s, d_idx, n, g.n_pad, d_periods,
                            bw, g.KP, exact_trig, wmat);
+    }
     PARRM_HIP_CHECK(hipGetLastError());
     const dim3 grid(g.nsplit, groups, g.nz);
     const bool narrow_ok = !getenv("PARRM_FIT_NO_NARROW16");  // (A/B knob: the 64-column form for every C <= 64)
-    const int K = 2 * bw + 1;
-    // W'W from three of its rows (GM = 2 of fit_accum_mfma_body) where the fast solvers rebuild it; the reference's
-    // operation order (sincos of the rounded k*a per harmonic) breaks the angle-addition identities at the 1e-10 of
-    // its argument rounding, so that mode keeps the full matrix.  PARRM_FIT_FULL_GRAM=1: the full matrix always.
-    const bool special = use_mfma && (K == 11 || K == 21 || K == 41) && !exact_trig && !getenv("PARRM_FIT_FULL_GRAM");
 #define PARRM_LAUNCH_ACCUM(NW_, CT_, THREADS_)                                                                              \
     do {                                                                                                                   \
         if (special)                                                                                                       \
@@ -1542,7 +1651,7 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         shape[p].g = fit_geometry(q.n_idx, q.n_chans, q.n_periods, q.bw);
         shape[p].inner = parrm_fit_workspace_bytes(q.n_idx, q.n_chans, q.n_periods, q.bw);
         const bool mfma_ok = q.ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(q.d_y) & 15) == 0 &&
-                             q.n_idx * q.ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(shape[p].g.n_pad) * 48 * 8 < 0x7fff0000LL;
+                             q.n_idx * q.ldy * 8 < 0x7fff0000LL && static_cast<int64_t>(shape[p].g.n_pad) * 48 * 8 * 3 < 0x7fff0000LL;
         if (!mfma_ok || q.n_idx >= (int64_t{1} << 30)) return PARRM_OK;
     }
     // host image: table | quarter flags | periods
@@ -1601,7 +1710,7 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         t.n_periods = static_cast<int>(q.n_periods);
         t.nsplit = g.nsplit;
         const int ncb = 48 / g.KP;
-        t.groups = (t.n_periods + ncb - 1) / ncb;
+        t.groups = g.packed ? g.groups : (t.n_periods + ncb - 1) / ncb;
         t.trig_blocks = (g.n_pad + 63) / 64;
         t.err_off = static_cast<int>(err_off[p]);
         quarters[slot] = (2 * q.bw + 1 == 41 && !getenv("PARRM_FIT_SOLVE_ONE_WORKGROUP")) ? g.KP : 0;
@@ -1626,8 +1735,11 @@ static int fit_errors_gang(const parrm_fit_problem *problems, int n_problems, Ho
         }
         const unsigned nz = static_cast<unsigned>(hi - lo);
         const GangProblem *sub = d_tab + lo;
-        hipLaunchKernelGGL(fit_trig_stacked_gang, dim3(max_trig, max_groups, nz), dim3(64 * ncb), 0, s, sub, bw, KP, exact);
-        const bool special = !exact && !getenv("PARRM_FIT_FULL_GRAM");  // (see fit_errors_impl)
+        const bool special = packed_form(bw);  // (one answer for the call: see fit_geometry)
+        if (special)
+            hipLaunchKernelGGL(fit_trig_packed_gang, dim3(max_trig, max_groups, nz), dim3(64 * packed_trig_waves(K)), 0, s, sub, bw, exact);
+        else
+            hipLaunchKernelGGL(fit_trig_stacked_gang, dim3(max_trig, max_groups, nz), dim3(64 * ncb), 0, s, sub, bw, KP, exact);
         const dim3 agrid(max_split, max_groups, nz);
 #define PARRM_LAUNCH_GANG(NW_, CT_, THREADS_)                                                                           \
     do {                                                                                                               \
