@@ -897,3 +897,35 @@ def test_gram_kernel_forms_return_the_same_bits(monkeypatch, n_chans, knob):
         rows = np.ascontiguousarray(y.cpu().numpy().T)
         ref = np.array([orc.fit_error_gathered(p, rows, n_chans, idx.cpu().numpy(), bw, 1.0) for p in periods[:3]])
         np.testing.assert_allclose(narrow[:3], ref, rtol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_chans", [3, 40, 100, 256, 300])
+def test_packed_three_row_gram_form_equals_the_full_product(monkeypatch, n_chans):
+    """Round 3's Gram form (design rows of the candidates packed without padding -- a candidate may straddle two 48-row
+    stacks --, W'W rebuilt in the solver from rows 0, K-2, K-1 by product-to-sum identities, natural-order
+    elimination) against the padded layout with the full product and LAPACK's pivoting (``PARRM_FIT_FULL_GRAM=1``):
+    every candidate count from 1 to 2 stacks' worth and a few ragged larger ones, all three bandwidths.  The two differ
+    in the rounding of W'W only (a few eps n per entry): 1e-13 relative on the errors; a slice of a grid planned as
+    the whole grid returns the whole grid's bits wherever its rows land in the packing."""
+    g = torch.Generator(device="cuda").manual_seed(100 + n_chans)
+    ws, ws_full = _hip.FitWorkspace(), _hip.FitWorkspace()  # (a workspace remembers the sizes of the form it was asked for)
+    for bw, n in ((5, 1777), (10, 3001), (20, 2500)):
+        y = torch.randn((n, (n_chans + 3) // 4 * 4), generator=g, device="cuda", dtype=torch.float64).clamp_(-3, 3)[:, :n_chans]
+        idx = torch.sort(torch.randperm(40000, device="cuda", generator=g)[:n]).values.to(torch.int64)
+        for n_per in list(range(1, 11)) + [13, 47, 48, 49, 131]:
+            periods = 169.2 * (1 + np.linspace(-2e-2, 2e-2, n_per)) if n_per > 1 else np.array([169.2359])
+            packed = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+            monkeypatch.setenv("PARRM_FIT_FULL_GRAM", "1")
+            full = _hip.fit_errors(y, idx, periods, bw, 1.0, ws_full)
+            monkeypatch.delenv("PARRM_FIT_FULL_GRAM")
+            assert np.all(np.isfinite(packed))
+            np.testing.assert_allclose(packed, full, rtol=1e-13, err_msg=f"bw {bw} n_per {n_per}")
+        periods = 169.2 * (1 + np.linspace(-2e-2, 2e-2, 131))
+        whole = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+        for lo, hi in ((0, 17), (17, 18), (18, 90), (90, 131)):
+            part = _hip.fit_errors(y, idx, periods[lo:hi], bw, 1.0, ws, grid_periods=131)
+            assert np.array_equal(part, whole[lo:hi]), (bw, lo, hi)
+    rows = np.ascontiguousarray(y.cpu().numpy().T)
+    ref = np.array([orc.fit_error_gathered(p, rows, n_chans, idx.cpu().numpy(), 20, 1.0) for p in periods[:3]])
+    np.testing.assert_allclose(whole[:3], ref, rtol=1e-9)
