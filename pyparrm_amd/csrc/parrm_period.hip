@@ -394,11 +394,6 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     const int u_lo = sl * per * 4;                     // steps of 4 samples
     const int u_hi = min(tiles, sl * per + per) * 4;
 
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(Y) + static_cast<int64_t>(zb) * kYCols, 0,
-        static_cast<int>((static_cast<int64_t>(n_idx) * ldy - static_cast<int64_t>(zb) * kYCols) * 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(Ws) + static_cast<int64_t>(pb) * n_pad * KS, 0, n_pad * KS * 8, 0x00020000);
     const int col0 = CT == 4 ? 64 * wv + 4 * c : CT * c;  // first of this lane's CT adjacent data columns
     // a quad may straddle n_chans: its extra columns come from the row's padding (or, with a tight
     // ldy, from the next row / the zero tail) and land in result columns that nothing reads
@@ -412,9 +407,6 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     const int K = kreal, g0 = KS * pb;    // (GM = 2) first global row of this stack
     const int n_stacks = GM == 2 ? (n_periods * K + KS - 1) / KS : 0;
     const int s_base = max(pb - 1, 0);
-    const __amdgpu_buffer_rsrc_t rs_sp = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(Ws) + static_cast<int64_t>(s_base) * n_pad * KS, 0,
-        GM == 2 ? min(3, n_stacks - s_base) * n_pad * KS * 8 : 0, 0x00020000);
     auto tile_of = [&](int k) -> int {  // column tile k of this wave
         return NW == 4 ? min(wv, 2) : (NW == 2 ? (wv == 0 ? k : 2) : k);
     };
@@ -447,49 +439,87 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         for (int ct = 0; ct < 3; ++ct) gacc[GM == 2 ? 0 : gr][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < (NS == 0 ? 1 : NS); ++k) gsp[k] = d4_t{0.0, 0.0, 0.0, 0.0};
-    double ra[D][3], ry[D][CT], rs[D][NS == 0 ? 1 : NS];
+    // Operand requests as inline assembly with hand-counted waits.  With compiler-visible loads hipcc either gathers
+    // the four steps' requests into one batch per iteration and rotates the operands through copies, or -- requests
+    // pinned behind each step's products -- cannot count across the loop's back edge and drains the queue
+    // (vmcnt(0)) at the top of every iteration: either way the prefetch depth is given up once per iteration and the
+    // matrix pipe idles for a memory latency (the launches sat at 87 % of the MFMA bound).  Loads retire in issue
+    // order among themselves and the loop issues nothing else, so "at most 3 steps' requests outstanding" means the
+    // oldest step's operands have landed.
+    constexpr int NYL = CT == 4 ? 2 : 1;                    // data requests per step
+    constexpr int LPS = NYL + 3 + (GM == 2 ? NS : 0);       // requests per step
+    // (raw buffer descriptors: base, 48-bit address | stride 0, byte count, the flags of make_buffer_rsrc above)
+    auto desc_of = [](const double *base, int bytes) -> u4_t {
+        const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+        return u4_t{static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(p))),
+                    static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(p >> 32))) & 0xffffu,
+                    static_cast<unsigned>(__builtin_amdgcn_readfirstlane(bytes)), 0x00020000u};
+    };
+    const u4_t dy = desc_of(Y + static_cast<int64_t>(zb) * kYCols,
+                            static_cast<int>((static_cast<int64_t>(n_idx) * ldy - static_cast<int64_t>(zb) * kYCols) * 8));
+    const u4_t dw = desc_of(Ws + static_cast<int64_t>(pb) * n_pad * KS, n_pad * KS * 8);
+    const u4_t dsp = desc_of(Ws + static_cast<int64_t>(s_base) * n_pad * KS,
+                             GM == 2 ? min(3, n_stacks - s_base) * n_pad * KS * 8 : 0);
+    u4_t qy[D][NYL];                          // data: CT = 4 two quads of 16 bytes, CT = 2 one; CT = 1: .x/.y only
+    u2_t qa[D][3], qs[D][NS == 0 ? 1 : NS];   // design rows of the three row tiles; special rows
     auto fetch = [&](int d) {
         if constexpr (CT == 4) {
-            const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
-            const u4_t y23 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy + 16, 0, 0);
-            ry[d][0] = __builtin_bit_cast(double, u2_t{y01.x, y01.y});
-            ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
-            ry[d][2] = __builtin_bit_cast(double, u2_t{y23.x, y23.y});
-            ry[d][3] = __builtin_bit_cast(double, u2_t{y23.z, y23.w});
+            asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16"
+                         : "=&v"(qy[d][0]), "=&v"(qy[d][1]) : "v"(vy), "s"(dy) : "memory");
         } else if constexpr (CT == 2) {
-            const u4_t y01 = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vy, 0, 0);
-            ry[d][0] = __builtin_bit_cast(double, u2_t{y01.x, y01.y});
-            ry[d][1] = __builtin_bit_cast(double, u2_t{y01.z, y01.w});
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(qy[d][0]) : "v"(vy), "s"(dy) : "memory");
         } else {
-            ry[d][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_y, vy, 0, 0));
+            u2_t one;
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(one) : "v"(vy), "s"(dy) : "memory");
+            qy[d][0].x = one.x;
+            qy[d][0].y = one.y;
         }
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
-            ra[d][rt] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw + rt * 128, 0, 0));
+        asm volatile("buffer_load_dwordx2 %0, %3, %4, 0 offen\n\tbuffer_load_dwordx2 %1, %3, %4, 0 offen offset:128\n\t"
+                     "buffer_load_dwordx2 %2, %3, %4, 0 offen offset:256"
+                     : "=&v"(qa[d][0]), "=&v"(qa[d][1]), "=&v"(qa[d][2]) : "v"(vw), "s"(dw) : "memory");
         if constexpr (GM == 2) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                rs[d][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_sp, vs[k], 0, 0));
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(qs[d][k]) : "v"(vs[k]), "s"(dsp) : "memory");
                 vs[k] += step_w;
             }
         }
         if (col_ok) vy += step_y;
         vw += step_w;
     };
+    // the step's operands have landed once at most the three younger steps' requests are outstanding; the "+v" ties
+    // make every use of them depend on this wait
+    auto landed = [&](int d) {
+        if constexpr (CT == 4)
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(qy[d][0]), "+v"(qy[d][1]), "+v"(qa[d][0]), "+v"(qa[d][1]), "+v"(qa[d][2])
+                         : "n"(3 * LPS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qy[d][0]), "+v"(qa[d][0]), "+v"(qa[d][1]), "+v"(qa[d][2])
+                         : "n"(3 * LPS) : "memory");
+        if constexpr (GM == 2) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) asm volatile("" : "+v"(qs[d][k]));
+        }
+    };
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(d);
     for (int u = u_lo; u < u_hi; u += D) {  // the slice is whole 16-sample tiles: a multiple of D steps
 #pragma unroll
         for (int d = 0; d < D; ++d) {
+            landed(d);
+            __builtin_amdgcn_sched_barrier(0);
             double a[3], y[CT];
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt) a[rt] = ra[d][rt];
-#pragma unroll
-            for (int t = 0; t < CT; ++t) y[t] = ry[d][t];
+            for (int rt = 0; rt < 3; ++rt) a[rt] = __builtin_bit_cast(double, qa[d][rt]);
+            y[0] = __builtin_bit_cast(double, u2_t{qy[d][0].x, qy[d][0].y});
+            if constexpr (CT >= 2) y[1] = __builtin_bit_cast(double, u2_t{qy[d][0].z, qy[d][0].w});
+            if constexpr (CT == 4) {
+                y[2] = __builtin_bit_cast(double, u2_t{qy[d][1].x, qy[d][1].y});
+                y[3] = __builtin_bit_cast(double, u2_t{qy[d][1].z, qy[d][1].w});
+            }
             double asp[NS == 0 ? 1 : NS];
 #pragma unroll
-            for (int k = 0; k < (NS == 0 ? 1 : NS); ++k) asp[k] = GM == 2 ? rs[d][k] : 0.0;
-            fetch(d);  // step u + d + D (past the end of the data: zeros)
+            for (int k = 0; k < (NS == 0 ? 1 : NS); ++k) asp[k] = GM == 2 ? __builtin_bit_cast(double, qs[d][k]) : 0.0;
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 yy[t] = fma(y[t], y[t], yy[t]);
@@ -533,6 +563,29 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
                     for (int ct = 0; ct < 3; ++ct)
                         gacc[gr][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gr], a[ct], gacc[gr][ct], 0, 0, 0);
             }
+            // the requests of step u + d + D (past the end of the data: zeros) go out AFTER this step's products have
+            // been issued, into the registers those have just read
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(d);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // The requests past the slice's end are still in flight here and the compiler does not know: it would compute the
+    // epilogue's addresses in their destination registers (dead, to its knowledge) and a late return would overwrite
+    // them (seen: a store through such an address faulted).  The ties BEHIND the wait keep every destination register
+    // allocated until the queue has drained.  (Requesting nothing in the last iteration instead makes the operands
+    // phi values, and the copies the compiler then places on the loop's back edge read registers whose data has not
+    // landed.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int k = 0; k < NYL; ++k) asm volatile("" : "+v"(qy[d][k]));
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) asm volatile("" : "+v"(qa[d][rt]));
+        if constexpr (GM == 2) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) asm volatile("" : "+v"(qs[d][k]));
         }
     }
     // y'y: the four sample lanes of a column hold partial sums
