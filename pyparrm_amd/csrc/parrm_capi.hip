@@ -3,7 +3,10 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <csignal>
 #include <cstring>
+#include <execinfo.h>
+#include <unistd.h>
 
 #include "parrm_common.h"
 
@@ -98,6 +101,34 @@ static bool is_pinned_range(const void *p, size_t bytes) {
     (void)hipGetLastError();  // attribute not available: the last byte must at least be page-locked too
     return is_pinned_host(static_cast<const char *>(p) + bytes - 1);
 }
+
+// Optional native backtrace when the process aborts (PARRM_ABORT_TRACE=1; tests/conftest.py sets it): an abort() raised
+// inside a library this one calls -- the HIP runtime, hipRTC's compiler -- otherwise leaves nothing but Python's own
+// stack in the log (round 3 met one such abort in a full test run, once, with no message).  backtrace() and
+// backtrace_symbols_fd() write straight to the descriptor; the handler that was installed before is restored and the
+// signal re-raised.
+namespace {
+void (*g_prev_abort_handler)(int) = SIG_DFL;
+void abort_trace_handler(int sig) {
+    static const char head[] = "\nparrm: SIGABRT -- native backtrace of the aborting thread:\n";
+    (void)!write(2, head, sizeof head - 1);
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, g_prev_abort_handler == SIG_IGN ? SIG_DFL : g_prev_abort_handler);  // (Python's faulthandler, if it was there)
+    raise(sig);
+}
+struct AbortTrace {
+    AbortTrace() {
+        if (getenv("PARRM_ABORT_TRACE")) {
+            void *warm[4];
+            (void)backtrace(warm, 4);  // (loads libgcc's unwinder now, not inside the handler)
+            g_prev_abort_handler = signal(SIGABRT, abort_trace_handler);
+            if (g_prev_abort_handler == SIG_ERR) g_prev_abort_handler = SIG_DFL;
+        }
+    }
+} g_abort_trace;
+}  // namespace
 
 // Optional trace of every lock / unlock this library performs (PARRM_HOST_TRACE=1, stderr): round 2 met a GPU page
 // fault at a heap address and could only argue about its cause afterwards -- the next one can be matched to a range.

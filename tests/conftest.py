@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# a native backtrace on stderr should the process abort inside a library (parrm_capi.hip, AbortTrace): read when the
+# HIP library is loaded
+os.environ.setdefault("PARRM_ABORT_TRACE", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
