@@ -519,12 +519,18 @@ def main():
             p32 = _hip.FilterPlan(state["filt"])
             x32 = x.to(torch.float32)
             y32 = torch.empty_like(x32)
-            roof(f"{rows} ch x {n_samples} float32 -> float32 (configs[4]'s dtype, resident)", "filter_phase_kernel<float,float> (packed)",
-                 launch_ms(lambda: p32.apply(x32, out=y32, out_dtype=torch.float32), 3), 8, rows, n_samples)
+
+            def name32(pl, out_t):
+                if pl.generated[0] == 1:
+                    return f"parrm_comb_kernel (generated, float32 widened into a float64 ring, {out_t} out)"
+                return f"filter_phase_kernel<float,{out_t}>" + (" (packed)" if out_t == "float" else "")
+
+            ms32 = launch_ms(lambda: p32.apply(x32, out=y32, out_dtype=torch.float32), 3)
+            roof(f"{rows} ch x {n_samples} float32 -> float32 (configs[4]'s dtype, resident)", name32(p32, "float"), ms32, 8, rows, n_samples)
             del y32
             y64 = torch.empty((rows, n_samples), dtype=torch.float64, device=x.device)
-            roof(f"{rows} ch x {n_samples} float32 -> float64 (the reference's dtype rule)", "filter_phase_kernel<float,double>",
-                 launch_ms(lambda: p32.apply(x32, out=y64), 3), 12, rows, n_samples)
+            ms64 = launch_ms(lambda: p32.apply(x32, out=y64), 3)
+            roof(f"{rows} ch x {n_samples} float32 -> float64 (the reference's dtype rule)", name32(p32, "double"), ms64, 12, rows, n_samples)
             del x32, y64
             out["extra"] = {"rooflines": extra}
         if cpu is not None:

@@ -190,12 +190,13 @@ struct Read {
 
 class Emitter {
    public:
-    explicit Emitter(const Geom &g, int batch) : g_(g), batch_(batch) {
+    explicit Emitter(const Geom &g, int batch, bool in32 = false, bool out32 = false)
+        : g_(g), batch_(batch), in32_(in32), out32_(out32) {
         // profiling ablations (results wrong by construction): 1 no tap reads, 2 no output stores, 4 no row requests,
         // 8 no second barrier, 16 no stage B at all, 32 no wait before the ring copy.  Part of the source text, so each has
         // its own code object.
         if (const char *e = getenv("PARRM_COMB_DEBUG")) debug_ = atoi(e);
-        if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0;
+        if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0 && !in32 && !out32;
     }
 
     // (base register, immediate) of element `col` of ring row m - a for lane row r, at ring phase km
@@ -348,6 +349,7 @@ class Emitter {
             const int ix = 2 * r;
             s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n";
             if (debug_ & 2) s << "          asm volatile(\"\" :: \"v\"(yv));\n";
+            else if (out32_) s << "          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, (float)yv), rsrc_y, yoff, " << r * g_.q * 4 << "u, 0);\n";
             else s << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n";
             s << "          S += eb" << ix + 1 << "; }\n";
             compute.push_back(s.str());
@@ -399,7 +401,7 @@ class Emitter {
     // compiler-visible loads) raises `irregular` and the next P waits drain.
     void emit_load_iter(std::ostringstream &o, int set, const std::string &kk) const {
         if (debug_ & 4) {
-            for (int i = 0; i < g_.nld; ++i) o << "        pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
+            for (int i = 0; i < g_.nld; ++i) o << "        pf" << set << "_" << i << " = PFZERO;\n";
             return;
         }
         // (nothing is requested beyond the stretch's last iteration: a load that lands after the loop would write
@@ -408,10 +410,11 @@ class Emitter {
         o << "        if ((" << kk << ") >= n_iter) {\n            irregular = " << g_.period << ";\n        } else {\n"
           << "        const long long lo = s0 + (long long)(NR * (" << kk << ") - ALO) * Q - HB;\n"
           << "        if (lo >= lim_lo && lo + (NR - 1) * Q + NCOL <= lim_hi) {\n"
-          << "            const u32 soff = (u32)((lo - a.buf_first) * 8);\n            asm volatile(";
+          << "            const u32 soff = (u32)((lo - a.buf_first) * XB);\n            asm volatile(";
         const int n = g_.nld;
+        // (float32 rows: 8-byte requests at 4-byte aligned addresses -- fine for buffer loads, checked on gfx950)
         for (int i = 0; i < n; ++i)
-            o << "\"buffer_load_dwordx4 %" << i << ", %" << n + i << ", %" << 2 * n << ", %" << 2 * n + 1 << " offen\\n\\t\"\n                         ";
+            o << "\"" << (in32_ ? "buffer_load_dwordx2" : "buffer_load_dwordx4") << " %" << i << ", %" << n + i << ", %" << 2 * n << ", %" << 2 * n + 1 << " offen\\n\\t\"\n                         ";
         o << "\"\"\n                         :";
         for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << "\"=&v\"(pf" << set << "_" << i << ")";
         o << "\n                         :";
@@ -419,7 +422,7 @@ class Emitter {
         o << ", \"s\"(xdesc), \"s\"(soff) : \"memory\");\n";
         o << "        } else {\n            irregular = " << g_.period << ";\n";
         for (int i = 0; i < g_.nld; ++i)
-            o << "            pf" << set << "_" << i << " = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, (goff" << i << " >> 31) ? -(1ll << 40) : lo + (long long)(goff" << i << " >> 3));\n";
+            o << "            pf" << set << "_" << i << " = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, (goff" << i << " >> 31) ? -(1ll << 40) : lo + (long long)(goff" << i << " >> XSH));\n";
         // (the empty asm makes the compiler wait for these loads HERE: left pending they would put its own
         // vmcnt(0) in front of the ring copy of every iteration that merges with this path)
         for (int i = 0; i < g_.nld; ++i) o << "            asm volatile(\"\" : \"+v\"(pf" << set << "_" << i << "));\n";
@@ -438,10 +441,14 @@ class Emitter {
         if (!(debug_ & 32))
             o << "        if (irregular > 0) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); --irregular; }\n"
               << "        else asm volatile(\"s_waitcnt vmcnt(" << std::min(63, younger_loads) << ")\" ::: \"memory\");\n";
+        // (a float32 recording is widened by ordinary arithmetic, which -- unlike the LDS store -- the "memory" clobber
+        // of the wait does not hold back: the ties make the conversions depend on the wait)
+        if (in32_)
+            for (int i = 0; i < g_.nld; ++i) o << "        asm volatile(\"\" : \"+v\"(pf" << set << "_" << i << "));\n";
         for (int i = 0; i < g_.nld; ++i) {
             o << "        ";
             if (partial && i == g_.nld - 1) o << "if (lvalid) ";
-            o << "*(LDS_AS u32x4 *)(loff" << i << " + " << sb << "u) = pf" << set << "_" << i << ";\n";
+            o << "*(LDS_AS u32x4 *)(loff" << i << " + " << sb << "u) = widen(pf" << set << "_" << i << ");\n";
         }
     }
 
@@ -452,6 +459,12 @@ class Emitter {
         o << "// generated by parrm_filter_comb.hip -- q " << g.q << ", C " << g.c << ", " << g.units.size() << " delta units\n";
         o << "typedef unsigned int u32;\ntypedef unsigned int u32x2 __attribute__((ext_vector_type(2)));\n"
           << "typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));\ntypedef double d2 __attribute__((ext_vector_type(2)));\n";
+        // element types: XT recording (XB bytes, XSH = log2), YT output (YB bytes); PFT = what one row request returns
+        // per lane (two samples) -- a float32 recording is widened to float64 on its way into the ring (widen()), the
+        // arithmetic is float64 throughout, a float32 output is rounded once at the store
+        o << "typedef " << (in32_ ? "float" : "double") << " XT;\n#define XB " << (in32_ ? 4 : 8) << "\n#define XSH " << (in32_ ? 2 : 3)
+          << "\ntypedef " << (out32_ ? "float" : "double") << " YT;\n#define YB " << (out32_ ? 4 : 8) << "\ntypedef "
+          << (in32_ ? "u32x2" : "u32x4") << " PFT;\n#define PFZERO " << (in32_ ? "(u32x2{0u, 0u})" : "(u32x4{0u, 0u, 0u, 0u})") << "\n";
         o << "#define LDS_AS __attribute__((address_space(3)))\n";
         o << "#define Q " << g.q << "\n#define CC " << g.c << "\n#define NR " << kNR << "\n#define MS " << g.ms << "\n#define HB " << g.hb
           << "\n#define NCOL " << g.ncol << "\n#define PB " << g.pb << "\n#define DPB " << g.dpb << "\n#define AHI " << g.a_hi
@@ -485,8 +498,8 @@ class Emitter {
         const std::string sdirect = sd.str();
         o << R"SRC(
 struct CombArgs {
-    const double *x;
-    double *y;
+    const XT *x;
+    YT *y;
     long long n_chans, buf_first, buf_len, out_first, out_len, n_total, ldx, ldy;
     const int *tapcum;
     long long stretch_len, n_stretch;
@@ -497,7 +510,7 @@ struct CombArgs {
 __device__ __forceinline__ u32 lds_off(const void *p) { return (u32)(size_t)(const LDS_AS void *)p; }
 
 // one output of a row that touches an end of the recording (divisor = taps inside the recording, parrm.py:862-866)
-__device__ __noinline__ void emit_edge(double *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
+__device__ __noinline__ void emit_edge(YT *yout, const int *tapcum, long long hw, long long n_total, double inv_taps,
                                        long long n, double xc, double s) {
     double y;
     if (n >= hw && n + hw < n_total) {
@@ -510,15 +523,33 @@ __device__ __noinline__ void emit_edge(double *yout, const int *tapcum, long lon
         if (w_hi >= w_lo) v = tapcum[w_hi + hw + 1] - tapcum[w_lo + hw];
         y = v > 0 ? xc - s / (double)v : s * 0.0;  // no tap inside: 0, a poisoned sum stays visible for the repair pass
     }
-    *yout = y;
+    *yout = (YT)y;
+}
+
+// two samples as the ring holds them (float64)
+__device__ __forceinline__ u32x4 widen(PFT v) {
+#if XB == 8
+    return v;
+#else
+    // (the components through scalars of their own: __builtin_bit_cast(float, v.y) on a vector component compiles to
+    // component 0 with this hipcc -- both halves of the chunk came out as the first sample)
+    const u32 s0_ = v.x, s1_ = v.y;
+    const u32x2 w0 = __builtin_bit_cast(u32x2, (double)__builtin_bit_cast(float, s0_));
+    const u32x2 w1 = __builtin_bit_cast(u32x2, (double)__builtin_bit_cast(float, s1_));
+    return u32x4{w0.x, w0.y, w1.x, w1.y};
+#endif
 }
 
 // samples n, n + 1 of a row, zero outside [lim_lo, lim_hi) (the ends of the recording / of the addressable window)
-__device__ __noinline__ u32x4 load_pair_padded(const double *xrow, long long buf_first, long long lim_lo, long long lim_hi, long long n) {
-    const double v0 = (n >= lim_lo && n < lim_hi) ? xrow[n - buf_first] : 0.0;
-    const double v1 = (n + 1 >= lim_lo && n + 1 < lim_hi) ? xrow[n + 1 - buf_first] : 0.0;
+__device__ __noinline__ PFT load_pair_padded(const XT *xrow, long long buf_first, long long lim_lo, long long lim_hi, long long n) {
+    const XT v0 = (n >= lim_lo && n < lim_hi) ? xrow[n - buf_first] : (XT)0;
+    const XT v1 = (n + 1 >= lim_lo && n + 1 < lim_hi) ? xrow[n + 1 - buf_first] : (XT)0;
+#if XB == 8
     const u32x2 w0 = __builtin_bit_cast(u32x2, v0), w1 = __builtin_bit_cast(u32x2, v1);
     return u32x4{w0.x, w0.y, w1.x, w1.y};
+#else
+    return u32x2{__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1)};
+#endif
 }
 
 extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArgs a) {
@@ -536,12 +567,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     if (s_end > a.out_first + a.out_len) s_end = a.out_first + a.out_len;
     const int rows_total = (int)((s_end - s0 + Q - 1) / Q);
     const int n_iter = (rows_total + NR - 1) / NR;
-    const double *xrow = a.x + ch * a.ldx;  // sample n at xrow[n - buf_first]
+    const XT *xrow = a.x + ch * a.ldx;  // sample n at xrow[n - buf_first]
     const long long lim_lo = a.buf_first > 0 ? a.buf_first : 0;
     long long lim_hi = a.buf_first + a.buf_len;
     if (lim_hi > a.n_total) lim_hi = a.n_total;
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xrow), 0, (int)(a.buf_len * 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y + ch * a.ldy, 0, (int)(a.out_len * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<XT *>(xrow), 0, (int)(a.buf_len * XB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y + ch * a.ldy, 0, (int)(a.out_len * YB), 0x00020000);
     const double inv_taps = a.inv_taps;
     // the same descriptor as four scalars, for the inline-asm row loads
     u32x4 xdesc;
@@ -549,7 +580,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
         const unsigned long long xp = (unsigned long long)xrow;
         xdesc.x = __builtin_amdgcn_readfirstlane((u32)xp);
         xdesc.y = __builtin_amdgcn_readfirstlane((u32)(xp >> 32) & 0xffffu);
-        xdesc.z = __builtin_amdgcn_readfirstlane((u32)(a.buf_len * 8));
+        xdesc.z = __builtin_amdgcn_readfirstlane((u32)(a.buf_len * XB));
         xdesc.w = 0x00020000u;
     }
     // > 0: the counted vmcnt of the ring copy does not hold (rows at the ends of the window are fetched by a
@@ -566,19 +597,23 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
         if (p_lo >= lim_lo && p_lo + (long long)(AHI - ALO + NR - 1) * Q + NCOL <= lim_hi) {
             // every row is addressable (all stretches but the first and the last of a recording): 16-byte buffer
             // loads, all in flight together
-            const u32 soff = (u32)((p_lo - a.buf_first) * 8);
+            const u32 soff = (u32)((p_lo - a.buf_first) * XB);
 #pragma unroll 3
             for (int t = tid; t < (AHI - ALO + NR) * CH16; t += NTHREADS) {
                 const int row = t / CH16, c16 = t - row * CH16;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (u32)(row * (Q * 8) + c16 * 16), soff, 0);
-                *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = v;
+#if XB == 8
+                const PFT v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (u32)(row * (Q * 8) + c16 * 16), soff, 0);
+#else
+                const PFT v = __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, (u32)(row * (Q * 4) + c16 * 8), soff, 0);
+#endif
+                *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = widen(v);
             }
         } else {
 #pragma unroll 1
             for (int t = tid; t < (AHI - ALO + NR) * CH16; t += NTHREADS) {
                 const int row = t / CH16, c16 = t - row * CH16;
                 const long long n = p_lo + (long long)row * Q + 2 * c16;
-                *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, n);
+                *(LDS_AS u32x4 *)(ring + (u32)((row + OFS - AHI) * PB + c16 * 16)) = widen(load_pair_padded(xrow, a.buf_first, lim_lo, lim_hi, n));
             }
         }
     }
@@ -600,16 +635,16 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
             const bool last_partial = (i == g.nld - 1) && (kNR * g.ch16 % kAThreads != 0);
             if (last_partial) {
                 o << "    const bool lvalid = lt" << i << " < NR * CH16;\n";
-                o << "    const u32 goff" << i << " = lvalid ? (u32)(lrow" << i << " * (Q * 8) + lc" << i << " * 16) : 0x80000000u;\n";
+                o << "    const u32 goff" << i << " = lvalid ? (u32)(lrow" << i << " * (Q * XB) + lc" << i << " * (2 * XB)) : 0x80000000u;\n";
 
             } else {
-                o << "    const u32 goff" << i << " = (u32)(lrow" << i << " * (Q * 8) + lc" << i << " * 16);\n";
+                o << "    const u32 goff" << i << " = (u32)(lrow" << i << " * (Q * XB) + lc" << i << " * (2 * XB));\n";
 
             }
             o << "    const u32 loff" << i << " = ring + (u32)(lrow" << i << " * PB + lc" << i << " * 16);\n";
         }
         for (int set = 0; set < P; ++set)
-            for (int i = 0; i < g.nld; ++i) o << "    u32x4 pf" << set << "_" << i << " = u32x4{0u, 0u, 0u, 0u};\n";
+            for (int i = 0; i < g.nld; ++i) o << "    PFT pf" << set << "_" << i << " = PFZERO;\n";
 
         // the two stage-A wave sets split each lane's C outputs; set 0 holds the stage-B waves and takes fewer
         int c_split = (g.c * 3 + 5) / 11;  // 3 of 11 (measured: 2 and 3 tie, 4 is 1 % slower, 5 is 2.5 % slower)
@@ -624,7 +659,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
                    << "        const long long nrow = s0 + (long long)kk * (NR * Q);\n"
                    << "        const bool fast = (kk + 1) * NR * (long long)Q + s0 <= s_end && nrow >= a.hw && nrow + NR * Q - 1 + a.hw < a.n_total;\n"
                    << "        if (fast) {\n          if (rho < Q" << ((debug_ & 16) ? " && false" : "") << ") {\n"
-                   << "          const u32 yoff = ystart + (u32)kk * (u32)(NR * Q * 8);\n          const u32 dbk = db + (u32)(kk & 1) * DBYTES;\n"
+                   << "          const u32 yoff = ystart + (u32)kk * (u32)(NR * Q * YB);\n          const u32 dbk = db + (u32)(kk & 1) * DBYTES;\n"
                    << "          const int rho2 = rho;\n          (void)rho2;\n";
             if (wide_b_) emit_stage_b_wide(bodies, kmb);
             else emit_stage_b(bodies, kmb);
@@ -657,7 +692,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     // stage-B lane
     const u32 xb0 = ring + (HB + rho) * 8, xb1 = xb0 + HSTEP;
     const u32 db = dbuf + rho * 8;
-    const u32 ystart = (u32)((s0 - a.out_first) * 8) + (u32)rho * 8u;
+    const u32 ystart = (u32)((s0 - a.out_first) * YB) + (u32)rho * (u32)YB;
     // stage B of iteration kk for rows that touch an end of the recording or of the stretch (and the last iteration)
     auto stage_b_generic = [&](int kk) {
         if (rho < Q) {
@@ -691,6 +726,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArg
     int batch_;
     int debug_ = 0;
     bool wide_b_ = false;  // stage B: two residues per lane, 16-byte reads and stores
+    bool in32_ = false, out32_ = false;  // float32 recording (widened to float64 on its way into the ring) / float32 output
 };
 
 // ---------------------------------------------------------------------------------------------- code objects
@@ -804,8 +840,8 @@ int pick_batch() {
 
 // device struct of the generated source
 struct CombArgs {
-    const double *x;
-    double *y;
+    const void *x;  // (XT * / YT * in the generated source)
+    void *y;
     long long n_chans, buf_first, buf_len, out_first, out_len, n_total, ldx, ldy;
     const int *tapcum;
     long long stretch_len, n_stretch;
@@ -817,6 +853,7 @@ struct CombArgs {
 
 struct CombKernel {
     Geom geom;
+    bool in32 = false, out32 = false;  // element types of the recording / the output (float32, else float64)
     std::string source;
     hipModule_t module = nullptr;
     hipFunction_t func = nullptr;
@@ -826,14 +863,16 @@ struct CombKernel {
 // Geometry + source for a tap mask (no device needed); nullptr when this kernel cannot take the filter.
 // `attempt` > 0: leaner variants for geometries whose first build spills registers (smaller read batches keep
 // fewer values in flight): the caller walks 0, 1, 2 until a build has no scratch.
-CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt) {
+CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt, bool in32, bool out32) {
     Geom g;
     if (!make_geom(tap, hw, q, &g)) return nullptr;
     if (attempt > 2) return nullptr;
     auto *k = new CombKernel();
     k->geom = g;
+    k->in32 = in32;
+    k->out32 = out32;
     const int batch = attempt == 0 ? pick_batch() : attempt == 1 ? 5 : 4;
-    k->source = Emitter(k->geom, batch).source();
+    k->source = Emitter(k->geom, batch, in32, out32).source();
     return k;
 }
 
@@ -901,7 +940,7 @@ int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw) {
     return best_q;
 }
 
-// Launch for float64 in / float64 out, mode 0.  Fills a->stretch_len / a->n_stretch (the repair pass needs them).
+// Launch (the kernel's own element types, mode 0).  Fills a->stretch_len / a->n_stretch (the repair pass needs them).
 int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     FilterArgs &a = *args;
     const Geom &g = k->geom;
@@ -947,8 +986,8 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     const int64_t blocks = a.n_chans * a.n_stretch;
     PARRM_REQUIRE(blocks <= 0x7fffffffLL, "filter: too many workgroups for one launch");
     CombArgs ca{};
-    ca.x = static_cast<const double *>(a.x);
-    ca.y = static_cast<double *>(a.y);
+    ca.x = a.x;
+    ca.y = a.y;
     ca.n_chans = a.n_chans;
     ca.buf_first = a.buf_first;
     ca.buf_len = a.buf_len;
@@ -968,10 +1007,9 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     return PARRM_OK;
 }
 
-// Can this launch take the comb kernel?  (float64 both sides is the caller's test.)
+// Can this launch take the comb kernel?  (31-bit byte offsets; the element types are the caller's match.)
 bool comb_accepts(const CombKernel *k, const FilterArgs &a) {
-    (void)k;
-    return a.buf_len * 8 < 0x7ffff000LL && a.out_len * 8 < 0x7ffff000LL;
+    return a.buf_len * (k->in32 ? 4 : 8) < 0x7ffff000LL && a.out_len * (k->out32 ? 4 : 8) < 0x7ffff000LL;
 }
 
 }  // namespace parrm_filter
@@ -991,7 +1029,10 @@ int parrm_filter_comb_precompile(const double *h_filter, int64_t filter_len, int
     for (int64_t i = 0; i < filter_len; ++i)
         if (i != hw && h_filter[i] != 0.0) tap[i] = 1;
     if (stride == 0) stride = parrm_filter::comb_search_stride(tap, hw);
-    parrm_filter::CombKernel *k = stride ? parrm_filter::comb_generate(tap, hw, stride, 0) : nullptr;
+    // (element types: float64 -> float64 unless PARRM_COMB_PRECOMPILE_TYPES says "f32f64" or "f32f32")
+    const char *types = getenv("PARRM_COMB_PRECOMPILE_TYPES");
+    const bool in32 = types && strncmp(types, "f32", 3) == 0, out32 = in32 && strcmp(types, "f32f32") == 0;
+    parrm_filter::CombKernel *k = stride ? parrm_filter::comb_generate(tap, hw, stride, 0, in32, out32) : nullptr;
     if (!k) {
         parrm::set_error("comb_precompile: the generated kernel does not take this filter");
         return PARRM_ERR_INVALID;

@@ -159,7 +159,8 @@ struct PhaseGeom {
 namespace parrm_filter {
 // parrm_filter_comb.hip: the per-filter generated kernel (float64 recordings, comb filters with q in [80, 176])
 struct CombKernel;
-CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt = 0);
+CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt = 0, bool in32 = false,
+                          bool out32 = false);
 void comb_destroy(CombKernel *k);
 bool comb_load(CombKernel *k);  // code object from the caches or hipRTC, loaded on the current device
 const char *comb_error(const CombKernel *k);
@@ -196,8 +197,11 @@ struct parrm_filter_plan {
     // Generated kernel (parrm_filter_comb.hip).  The tap mask is kept so that the kernel can be generated at the
     // first launch large enough to pay for a compile; comb_state: 0 not tried, 1 loaded, -1 unavailable.
     std::vector<int8_t> tap_mask;
-    mutable parrm_filter::CombKernel *comb = nullptr;
-    mutable int comb_state = 0;
+    // One kernel per pair of element types (kCombVariants: 0 = float64 -> float64, 1 = float32 -> float64,
+    // 2 = float32 -> float32); comb_last = the variant the last launch asked for (parrm_filter_plan_generated).
+    mutable parrm_filter::CombKernel *comb[3] = {nullptr, nullptr, nullptr};
+    mutable int comb_state[3] = {0, 0, 0};
+    mutable int comb_last = 0;
 };
 
 

@@ -101,9 +101,11 @@ def test_generated_kernel_is_the_default_for_large_float64_launches_only(monkeyp
     big = _hip.FilterPlan(filt)
     y = big.apply(x)
     _in_use(big)
+    monkeypatch.setenv("PARRM_F32_PACKED", "1")
     f32 = _hip.FilterPlan(filt)
-    f32.apply(x.to(torch.float32))
+    f32.apply(x.to(torch.float32), out_dtype=torch.float32)  # (the packed phase-major kernel on request)
     assert f32.generated[0] == 0
+    monkeypatch.delenv("PARRM_F32_PACKED")
     monkeypatch.setenv("PARRM_COMB", "0")
     off = _hip.FilterPlan(filt)
     y_generic = off.apply(x)
@@ -219,3 +221,55 @@ def test_generated_kernel_one_sided_filters_with_omitted_samples(monkeypatch):
         _in_use(plan, may_decline=True)
         ref = orc.filter_data_direct(x, filt)
         assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), (period, hw, omit, direction)
+
+
+def test_generated_kernel_float32_recordings(monkeypatch):
+    """Round 3: float32 recordings through the generated kernel -- widened to float64 on their way into the ring, float64
+    arithmetic throughout.  float32 -> float64 (the reference's dtype rule) equals the closed form on the widened
+    samples to 1e-10; float32 -> float32 is the float64 result rounded once (<= 1.2e-7 of the largest output; the packed
+    phase-major kernel's float32 sums, PARRM_F32_PACKED=1 and every small launch, are within 6e-6).  Windows, both
+    ends, non-finite samples as for float64."""
+    period = 22000 / 130 * (1 + 3e-5)
+    rng = np.random.default_rng(41)
+    monkeypatch.setenv("PARRM_COMB", "force")
+    for direction, omit, n in (("both", 0, 300_017), ("past", 3, 200_003)):
+        filt, hw = _default_filter(period, n, omit, direction)
+        x = rng.standard_normal((3, n)).astype(np.float32)
+        x[1, 777] = np.nan
+        x[2, n - 5] = np.inf
+        ref = orc.filter_data_direct(x.astype(np.float64), filt)
+        scale = np.abs(ref).max()
+        plan = _hip.FilterPlan(filt)
+        d_x = torch.from_numpy(x).cuda()
+        y64 = plan.apply(d_x, out_dtype=torch.float64).cpu().numpy()
+        _in_use(plan)
+        assert np.array_equal(y64 == 0, ref == 0)
+        assert np.abs(y64 - ref).max() <= TOL * scale, direction
+        o0, olen = n // 3 + 1, n // 4
+        b0, b1 = max(o0 - hw, 0), min(o0 + olen + hw, n)
+        part = plan.apply_window(torch.from_numpy(np.ascontiguousarray(x[:, b0:b1])).cuda(), b0, o0, olen, n).cpu().numpy()
+        assert np.abs(part - ref[:, o0:o0 + olen]).max() <= TOL * scale, (direction, "window")
+        # float32 output: the generated kernel too; the packed phase-major kernel on request
+        y32 = plan.apply(d_x, out_dtype=torch.float32).cpu().numpy()
+        _in_use(plan)
+        monkeypatch.setenv("PARRM_F32_PACKED", "1")
+        packed_plan = _hip.FilterPlan(filt)
+        packed = packed_plan.apply(d_x, out_dtype=torch.float32).cpu().numpy()
+        assert packed_plan.generated[0] == 0
+        monkeypatch.delenv("PARRM_F32_PACKED")
+        assert y32.dtype == np.float32 and np.array_equal(y32 == 0, ref == 0)
+        assert np.abs(y32 - ref).max() <= 1.2e-7 * scale, direction
+        assert np.abs(packed - ref).max() <= 1e-5 * scale
+
+
+def test_generated_kernel_is_the_default_for_large_float32_to_float64_launches(monkeypatch):
+    monkeypatch.delenv("PARRM_COMB", raising=False)
+    filt, _ = _default_filter(22000 / 130 * (1 + 3e-5), 10_000_000)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((32, 1_200_000), dtype=torch.float32, device="cuda", generator=g)
+    plan = _hip.FilterPlan(filt)
+    y = plan.apply(x, out_dtype=torch.float64)
+    _in_use(plan)
+    monkeypatch.setenv("PARRM_COMB", "0")
+    generic = _hip.FilterPlan(filt).apply(x, out_dtype=torch.float64)
+    assert (y - generic).abs().max().item() <= TOL * generic.abs().max().item()

@@ -266,7 +266,7 @@ def test_config3_find_period_stage_by_stage_vs_oracle():
     # per channel, as the reference does: a K = 41 candidate costs it seconds) -- and more candidates on a 32-channel
     # subset of the same stage matrix, 8x cheaper, so that the test stays within minutes on a slow host
     budget = {0: 16, 1: 6, 2: 1}
-    subset_budget = {0: 16, 1: 8, 2: 6}
+    subset_budget = {0: 16, 1: 8, 2: 3}
     sub = slice(64, 96)
     for run, t in enumerate(trace[:3]):
         idx = t["indices"]
@@ -280,15 +280,23 @@ def test_config3_find_period_stage_by_stage_vs_oracle():
         errors, grid = t["errors"], t["grid"]
         order = np.argsort(errors)
         starts = order[:5]
-        sample = np.unique(np.concatenate([starts, rng.choice(len(grid), budget[run], replace=False)]))
+        # (stage 3: a 41-row design matrix per channel costs the oracle ~12 s per candidate on 256 channels -- the best
+        # two starts there, all five on the 32-channel subset below)
+        full_starts = starts if run < 2 else starts[:2]
+        sample = np.unique(np.concatenate([full_starts, rng.choice(len(grid), budget[run], replace=False)]))
         ref = np.array([orc.fit_error_gathered(grid[i], std_cols, n_chans, idx, bw, 1.0) for i in sample])
         np.testing.assert_allclose(errors[sample], ref, rtol=1e-9)
-        # the five starts come out in the oracle's order too
-        ref_starts = np.array([ref[np.searchsorted(sample, i)] for i in starts])
+        # the starts come out in the oracle's order too
+        ref_starts = np.array([ref[np.searchsorted(sample, i)] for i in full_starts])
         assert np.all(np.diff(ref_starts) >= 0)
         # the same kernels on a 32-channel subset of the stage matrix
         y_dev = _hip.gather_standardise(x, d_idx, d_scale, 3.0)
         y_sub = y_dev[:, sub].contiguous()
+        if run == 2:
+            got_starts = _hip.fit_errors(y_sub, d_idx, grid[starts], bw, 1.0)
+            ref_starts = np.array([orc.fit_error_gathered(grid[i], std_cols[sub], 32, idx, bw, 1.0) for i in starts])
+            np.testing.assert_allclose(got_starts, ref_starts, rtol=1e-9)
+            assert np.array_equal(np.argsort(got_starts), np.argsort(ref_starts))
         more = rng.choice(len(grid), subset_budget[run], replace=False)
         got_sub = _hip.fit_errors(y_sub, d_idx, grid[more], bw, 1.0)
         ref_sub = np.array([orc.fit_error_gathered(grid[i], std_cols[sub], 32, idx, bw, 1.0) for i in more])
