@@ -102,7 +102,10 @@ int parrm_filter_plan_set_kernel(parrm_filter_plan *plan, int kernel);
 /* Whole recording resident on the device: x[n_chans][n_samples] -> y[n_chans][n_samples].
  * x_dtype in {PARRM_F32, PARRM_F64}; y_dtype PARRM_F64 (the reference's dtype rule: float32
  * in -> float64 out) or PARRM_F32 (build option, only with x_dtype PARRM_F32).  x and y
- * must not overlap. */
+ * must not overlap.  Arithmetic: float64 throughout for float64 output; for float32 output, launches
+ * of >= 2^25 samples whose filter the generated kernel takes are float64 arithmetic rounded once (within
+ * 1.2e-7 of the largest output), all others sum a row's tap values in float32 (within 6e-6);
+ * PARRM_F32_PACKED=1 selects the latter always. */
 int parrm_filter_apply(const parrm_filter_plan *plan, const void *d_x, int x_dtype, void *d_y,
                        int y_dtype, int64_t n_chans, int64_t n_samples, int64_t ldx,
                        int64_t ldy, void *stream);
