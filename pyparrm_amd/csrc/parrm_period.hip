@@ -97,6 +97,20 @@ __device__ inline Blk this_block() {
 }
 constexpr int kMaxBw = 23;
 
+// An optimiser batch's candidate periods travel as a kernel ARGUMENT of the design-matrix kernel (<= kSmallPeriods of
+// them): the H2D copy they used to take was a blit kernel of its own in front of every batch (~4 us + ~4.5 us of
+// dispatch gap + the host's hipMemcpyAsync, 76 times per search).
+// The struct is the kernels' FIRST parameter and is never named in their bodies: indexing a by-value aggregate with a
+// run-time index makes hipcc copy it into scratch in every thread (measured: 520 bytes of private segment per lane,
+// find_period 25 -> 33 ms); the values are read where the dispatch packet put them, at the start of the kernarg segment.
+constexpr int kSmallPeriods = 64;
+struct SmallPeriods {
+    double p[kSmallPeriods];
+};
+__device__ __forceinline__ const double *small_periods_in_kernarg() {
+    return (const double *)__builtin_amdgcn_kernarg_segment_ptr();  // (a C cast: it crosses the address space)
+}
+
 __host__ __device__ inline int kp_for(int bw) {  // padded row count: 4 waves x KT rows
     const int K = 2 * bw + 1;
     return K <= 12 ? 12 : (K <= 24 ? 24 : 48);
@@ -109,9 +123,10 @@ __host__ __device__ inline int kp_for(int bw) {  // padded row count: 4 waves x 
 //               (error ~ k*eps; the reference's own sin(fl(k*a)) carries ~eps*k*a/2 ~ 1e-10 of
 //               argument rounding at a ~ 1e5 rad, so the two agree to that level);
 //   exact == 1: sincos(fl(k*a)) per harmonic, the reference's operation order (:622-623).
-__global__ void __launch_bounds__(256) fit_trig_kernel(const int64_t *idx, int n_idx, int n_pad,
+__global__ void __launch_bounds__(256) fit_trig_kernel(const SmallPeriods, const int64_t *idx, int n_idx, int n_pad,
                                                         const double *periods, int bw, int kpc, int exact,
-                                                        double *W) {
+                                                        double *W, int by_value) {
+    if (by_value) periods = small_periods_in_kernarg();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = blockIdx.y;
     if (j >= n_pad) return;
@@ -179,10 +194,11 @@ __device__ __forceinline__ void fit_trig_stacked_body(const int64_t *idx, int n_
     double *dst = Ws + (static_cast<int64_t>(blk.y) * n_pad + static_cast<int64_t>(blk.x) * 64) * KS;
     for (int e = threadIdx.x; e < rows * KS; e += blockDim.x) dst[e] = tile[(e / KS) * TS + (e % KS)];
 }
-__global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const int64_t *idx, int n_idx, int n_pad,
+__global__ void __launch_bounds__(256) fit_trig_stacked_kernel(const SmallPeriods, const int64_t *idx, int n_idx, int n_pad,
                                                                 const double *periods, int n_periods, int bw,
-                                                                int kpc, int exact, double *Ws) {
-    fit_trig_stacked_body(idx, n_idx, n_pad, periods, n_periods, bw, kpc, exact, Ws, this_block());
+                                                                int kpc, int exact, double *Ws, int by_value) {
+    fit_trig_stacked_body(idx, n_idx, n_pad, by_value ? small_periods_in_kernarg() : periods, n_periods, bw, kpc, exact, Ws,
+                          this_block());
 }
 
 // The PACKED stacked layout (GM = 2 of fit_accum_mfma_body): global row K p + k for row k of candidate p, stack
@@ -230,10 +246,11 @@ __device__ __forceinline__ void fit_trig_packed_body(const int64_t *idx, int n_i
     double *dst = Ws + (static_cast<int64_t>(blk.y) * n_pad + static_cast<int64_t>(blk.x) * 64) * KS;
     for (int e = threadIdx.x; e < rows * KS; e += blockDim.x) dst[e] = tile[(e / KS) * TS + (e % KS)];
 }
-__global__ void __launch_bounds__(384) fit_trig_packed_kernel(const int64_t *idx, int n_idx, int n_pad,
+__global__ void __launch_bounds__(384) fit_trig_packed_kernel(const SmallPeriods, const int64_t *idx, int n_idx, int n_pad,
                                                                const double *periods, int n_periods, int bw, int exact,
-                                                               double *Ws) {
-    fit_trig_packed_body(idx, n_idx, n_pad, periods, n_periods, bw, exact, Ws, this_block());
+                                                               double *Ws, int by_value) {
+    fit_trig_packed_body(idx, n_idx, n_pad, by_value ? small_periods_in_kernarg() : periods, n_periods, bw, exact, Ws,
+                         this_block());
 }
 
 // ---- Gram blocks -----------------------------------------------------------------------------
@@ -1494,6 +1511,7 @@ struct Publish {
     volatile unsigned long long *flag;
     unsigned long long seq;
     bool done;
+    const double *h_periods;  // the batch's periods on the host (<= kSmallPeriods: passed by value, d_periods unused)
 };
 static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx, int64_t n_chans,
                            const double *d_periods, int64_t n_periods, int64_t grid_periods, int bw, double lambda,
@@ -1540,15 +1558,18 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
     const int K = 2 * bw + 1;
     const bool special = use_mfma && g.packed;  // packed rows, W'W from three of its rows (fit_accum_mfma_body GM = 2)
     const int groups = special ? g.groups : (P + ncb - 1) / ncb;
+    SmallPeriods small{};
+    const int by_value = pub && pub->h_periods && P <= kSmallPeriods;
+    if (by_value) std::memcpy(small.p, pub->h_periods, static_cast<size_t>(P) * sizeof(double));
     if (special) {
         hipLaunchKernelGGL(fit_trig_packed_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * packed_trig_waves(K)), 0, s,
-                           d_idx, n, g.n_pad, d_periods, P, bw, exact_trig, wmat);
+                           small, d_idx, n, g.n_pad, d_periods, P, bw, exact_trig, wmat, by_value);
     } else if (use_mfma) {
-        hipLaunchKernelGGL(fit_trig_stacked_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * ncb), 0, s, d_idx, n,
-                           g.n_pad, d_periods, P, bw, g.KP, exact_trig, wmat);
+        hipLaunchKernelGGL(fit_trig_stacked_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * ncb), 0, s, small, d_idx, n,
+                           g.n_pad, d_periods, P, bw, g.KP, exact_trig, wmat, by_value);
     } else {
-        hipLaunchKernelGGL(fit_trig_kernel, dim3((g.n_pad + 255) / 256, P), dim3(256), 0, s, d_idx, n, g.n_pad, d_periods,
-                           bw, g.KP, exact_trig, wmat);
+        hipLaunchKernelGGL(fit_trig_kernel, dim3((g.n_pad + 255) / 256, P), dim3(256), 0, s, small, d_idx, n, g.n_pad,
+                           d_periods, bw, g.KP, exact_trig, wmat, by_value);
     }
     PARRM_HIP_CHECK(hipGetLastError());
     const dim3 grid(g.nsplit, groups, g.nz);
@@ -1641,14 +1662,14 @@ int parrm_fit_errors_host(const double *d_y, int64_t ldy, const int64_t *d_idx, 
     PARRM_HIP_CHECK(hipGetDevice(&dev));
     if (n_periods <= HostStage::kCap && !getenv("PARRM_FIT_COPY_PATH") && thread_stage().ready(dev)) {
         HostStage &st = thread_stage();
-        // (the periods still go through a device copy: every workgroup of the trig kernel reads them,
-        // which would be one uncached PCIe read per wave from mapped host memory)
-        // (also measured: the periods as kernel arguments of a one-wave launch instead of this copy -- no difference)
-        PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
+        // (<= kSmallPeriods: by value with the design-matrix kernel's launch; more: a device copy -- every workgroup of
+        // that kernel reads them, which from mapped host memory would be one uncached PCIe read per wave)
+        const bool by_value = n_periods <= kSmallPeriods && !getenv("PARRM_FIT_PERIODS_BY_COPY");
+        if (!by_value) PARRM_HIP_CHECK(hipMemcpyAsync(d_per, h_periods, n_periods * sizeof(double), hipMemcpyHostToDevice, s));
         const unsigned long long seq = ++st.seq;
         volatile unsigned long long *h_flag = reinterpret_cast<volatile unsigned long long *>(st.h + 2 * HostStage::kCap);
         Publish pub{st.d + HostStage::kCap, reinterpret_cast<volatile unsigned long long *>(st.d + 2 * HostStage::kCap), seq,
-                    false};
+                    false, by_value ? h_periods : nullptr};
         const int rc = fit_errors_impl(d_y, ldy, d_idx, n_idx, n_chans, d_per, n_periods, n_periods, bw, lambda, d_err,
                                        d_workspace, inner, stream, &pub);
         if (rc != PARRM_OK) return rc;
