@@ -188,6 +188,11 @@ struct Read {
     int imm;
 };
 
+// (one name per pair of element types: a profiler's kernel trace tells the variants apart)
+inline const char *kernel_name(bool in32, bool out32) {
+    return !in32 ? "parrm_comb_kernel" : (out32 ? "parrm_comb_kernel_f32_f32" : "parrm_comb_kernel_f32_f64");
+}
+
 class Emitter {
    public:
     explicit Emitter(const Geom &g, int batch, bool in32 = false, bool out32 = false)
@@ -464,7 +469,8 @@ class Emitter {
         // arithmetic is float64 throughout, a float32 output is rounded once at the store
         o << "typedef " << (in32_ ? "float" : "double") << " XT;\n#define XB " << (in32_ ? 4 : 8) << "\n#define XSH " << (in32_ ? 2 : 3)
           << "\ntypedef " << (out32_ ? "float" : "double") << " YT;\n#define YB " << (out32_ ? 4 : 8) << "\ntypedef "
-          << (in32_ ? "u32x2" : "u32x4") << " PFT;\n#define PFZERO " << (in32_ ? "(u32x2{0u, 0u})" : "(u32x4{0u, 0u, 0u, 0u})") << "\n";
+          << (in32_ ? "u32x2" : "u32x4") << " PFT;\n#define PFZERO " << (in32_ ? "(u32x2{0u, 0u})" : "(u32x4{0u, 0u, 0u, 0u})")
+          << "\n#define KNAME " << kernel_name(in32_, out32_) << "\n";
         o << "#define LDS_AS __attribute__((address_space(3)))\n";
         o << "#define Q " << g.q << "\n#define CC " << g.c << "\n#define NR " << kNR << "\n#define MS " << g.ms << "\n#define HB " << g.hb
           << "\n#define NCOL " << g.ncol << "\n#define PB " << g.pb << "\n#define DPB " << g.dpb << "\n#define AHI " << g.a_hi
@@ -552,7 +558,7 @@ __device__ __noinline__ PFT load_pair_padded(const XT *xrow, long long buf_first
 #endif
 }
 
-extern "C" __global__ void __launch_bounds__(NTHREADS) parrm_comb_kernel(CombArgs a) {
+extern "C" __global__ void __launch_bounds__(NTHREADS) KNAME(CombArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
     const u32 ring = lds_off(smem);
     const u32 dbuf = ring + RING_BYTES;
@@ -888,7 +894,7 @@ bool comb_load(CombKernel *k) {
     std::vector<char> code;
     if (!code_for_source(k->source, &code, &k->error)) return false;
     hipError_t e = hipModuleLoadData(&k->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&k->func, k->module, "parrm_comb_kernel");
+    if (e == hipSuccess) e = hipModuleGetFunction(&k->func, k->module, kernel_name(k->in32, k->out32));
     int scratch = 0;
     if (e == hipSuccess) e = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->func);
     if (e == hipSuccess && scratch != 0) {

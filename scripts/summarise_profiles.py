@@ -37,7 +37,7 @@ def counter(kind, name):
     path = glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True)[0]
     vals = []
     for r in csv.DictReader(open(path)):
-        if ("parrm_comb_kernel" in r["Kernel_Name"] or "filter_phase_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == name:
+        if (r["Kernel_Name"].strip() == "parrm_comb_kernel" or "filter_phase_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == name:
             vals.append(float(r["Counter_Value"]))
     return vals
 
