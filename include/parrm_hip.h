@@ -129,6 +129,32 @@ int parrm_filter_apply_block(const parrm_filter_plan *plan, const void *d_x, int
                              int64_t buf_len, int64_t out_first, int64_t out_len, int64_t n_total,
                              int64_t ldx, int64_t ldy, void *stream);
 
+/* ---- Nelder-Mead refinement of period estimates (a8) --------------------------------------------------------
+ * Replaces /root/reference/src/pyparrm/parrm.py:510-517 and :545-550 (scipy.optimize.fmin per start, mapped over
+ * the <= 5 best candidates of a stage, and once more for the final polish): SciPy's one-parameter run (rho 1, chi 2,
+ * psi 0.5, sigma 0.5, initial simplex {x0, 1.05 x0}, xatol = fatol as given, maxiter = maxfun = 200 when < 0) for
+ * several starts in lock-step, the objective evaluated in BATCHES of abscissae: reflection + both contractions of
+ * every run in flight (expansion / shrink points in small follow-up batches), and while at most `lookahead_runs`
+ * runs are in flight also the points of the likely following step.  Decisions are SciPy's, taken from the same
+ * values in the same order; pyparrm_amd/_neldermead.py is the same logic in Python and tests/test_neldermead.py
+ * holds the two (and scipy.optimize.fmin) equal. */
+typedef struct parrm_nm parrm_nm;
+int parrm_nm_create(const double *starts, int n_starts, double xatol, double fatol, int maxiter, int maxfun,
+                    int lookahead_runs, parrm_nm **nm);
+int parrm_nm_destroy(parrm_nm *nm);
+/* Step interface: the next batch of abscissae (ascending; *n = 0: every run has ended), then their values. */
+int parrm_nm_next(parrm_nm *nm, double *points, int capacity, int *n);
+int parrm_nm_feed(parrm_nm *nm, const double *values, int n);
+/* (xopt, fopt, iterations, function calls) of run `run`: fmin(..., full_output=True)[:4]. */
+int parrm_nm_result(const parrm_nm *nm, int run, double *xopt, double *fopt, int *iterations, int *funcalls);
+/* The whole search on the device objective (parrm_fit_errors_host per batch) in one call.  Workspace:
+ * parrm_nm_fit_workspace_bytes.  hist_x / hist_f / batch_sizes (may be NULL): every evaluation, batch by batch. */
+size_t parrm_nm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int bw);
+int parrm_nm_minimise_fit(parrm_nm *nm, const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
+                          int64_t n_chans, int bw, double lambda, void *d_workspace, size_t workspace_bytes, void *stream,
+                          double *hist_x, double *hist_f, int hist_capacity, int *batch_sizes, int batch_capacity,
+                          int *n_batches);
+
 /* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host uses buffers that are
  * already page-locked in place (the fast path) -- the WHOLE range must lie inside one registration -- and
  * stages every other buffer through page-locked buffers of the call's own: it never locks caller memory

@@ -48,6 +48,13 @@ SYMBOLS = (
     "parrm_fit_errors_slice",
     "parrm_fit_errors_host",
     "parrm_fit_errors_multi",
+    "parrm_nm_create",
+    "parrm_nm_destroy",
+    "parrm_nm_next",
+    "parrm_nm_feed",
+    "parrm_nm_result",
+    "parrm_nm_fit_workspace_bytes",
+    "parrm_nm_minimise_fit",
 )
 
 
@@ -184,6 +191,21 @@ def lib() -> C.CDLL:
         L.parrm_fit_errors_host.argtypes = [vp, i64, vp, i64, i64, vp, i64, i32, dbl, vp, vp, C.c_size_t, vp]
         L.parrm_fit_errors_multi.restype = i32
         L.parrm_fit_errors_multi.argtypes = [C.POINTER(FitProblem), i32, vp]
+        L.parrm_nm_create.restype = i32
+        L.parrm_nm_create.argtypes = [vp, i32, dbl, dbl, i32, i32, i32, C.POINTER(vp)]
+        L.parrm_nm_destroy.restype = i32
+        L.parrm_nm_destroy.argtypes = [vp]
+        L.parrm_nm_next.restype = i32
+        L.parrm_nm_next.argtypes = [vp, vp, i32, C.POINTER(i32)]
+        L.parrm_nm_feed.restype = i32
+        L.parrm_nm_feed.argtypes = [vp, vp, i32]
+        L.parrm_nm_result.restype = i32
+        L.parrm_nm_result.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
+        L.parrm_nm_fit_workspace_bytes.restype = C.c_size_t
+        L.parrm_nm_fit_workspace_bytes.argtypes = [i64, i64, i32]
+        L.parrm_nm_minimise_fit.restype = i32
+        L.parrm_nm_minimise_fit.argtypes = [vp, vp, i64, vp, i64, i64, i32, dbl, vp, C.c_size_t, vp, vp, vp, i32, vp, i32,
+                                            C.POINTER(i32)]
         if L.parrm_hip_abi_version() != 2:
             raise HipLibraryError("libparrm_hip.so has an unexpected ABI version (rebuild it: make -C pyparrm_amd/csrc)")
         _lib = L
@@ -194,6 +216,7 @@ def lib() -> C.CDLL:
 
 
 _SHUT_DOWN = False
+dbl_t = C.c_double
 _LIVE_PLANS: set = set()  # weak references to every FilterPlan alive
 
 
@@ -652,6 +675,75 @@ class FitWorkspace:
             self._d_per = torch.empty(cap, dtype=torch.float64, device=device)
             self._d_err = torch.empty(cap, dtype=torch.float64, device=device)
         return self._h_per, self._h_err, self._d_per, self._d_err
+
+
+class NativeNelderMead:
+    """The lock-step Nelder-Mead of ``pyparrm_amd/_neldermead.py`` in the C library (``csrc/parrm_nm.hip``): the same
+    batches, the same decisions.  Step interface (``next_batch`` / ``feed``: needs no GPU -- tests drive it against
+    the Python generator) and the whole search on the device objective in one C call (``minimise_fit``)."""
+
+    MAX_BATCH = 64
+
+    def __init__(self, starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None, lookahead_runs=2):
+        x0 = np.ascontiguousarray(np.asarray(starts, dtype=np.float64).reshape(-1))
+        self._n = int(x0.shape[0])
+        h = C.c_void_p()
+        check(lib().parrm_nm_create(x0.ctypes.data, self._n, float(xtol), float(ftol), -1 if maxiter is None else int(maxiter),
+                                    -1 if maxfun is None else int(maxfun), int(lookahead_runs), C.byref(h)), "parrm_nm_create")
+        self._h = h
+        self._buf = np.empty(self.MAX_BATCH, dtype=np.float64)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and not _SHUT_DOWN and _lib is not None:  # (interpreter shutdown may have cleared the module already)
+            try:
+                _lib.parrm_nm_destroy(h)
+            except Exception:
+                pass
+
+    def next_batch(self):
+        """The next batch of abscissae (ascending float64 array), or None when every run has ended."""
+        n = C.c_int32(0)
+        check(lib().parrm_nm_next(self._h, self._buf.ctypes.data, self.MAX_BATCH, C.byref(n)), "parrm_nm_next")
+        return self._buf[: n.value].copy() if n.value else None
+
+    def feed(self, values) -> None:
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        check(lib().parrm_nm_feed(self._h, v.ctypes.data, int(v.shape[0])), "parrm_nm_feed")
+
+    def results(self):
+        """``[(xopt[1], fopt, iterations, funcalls)]`` per start, as ``fmin_lockstep`` returns them."""
+        out = []
+        x, f, it, nf = dbl_t(), dbl_t(), C.c_int32(), C.c_int32()
+        for r in range(self._n):
+            check(lib().parrm_nm_result(self._h, r, C.byref(x), C.byref(f), C.byref(it), C.byref(nf)), "parrm_nm_result")
+            out.append((np.array([x.value], dtype=np.float64), float(f.value), int(it.value), int(nf.value)))
+        return out
+
+    def minimise_fit(self, y, idx, bandwidth: int, lambda_: float, workspace: "FitWorkspace"):
+        """Run the search to its end on the harmonic-regression objective of the stage matrix ``y`` / indices ``idx``
+        (device tensors); returns ``(results, log)`` with ``log`` the list of ``(points, errors)`` per batch."""
+        torch = require_gpu()
+        n_idx, n_chans = (int(v) for v in y.shape)
+        nbytes = int(lib().parrm_nm_fit_workspace_bytes(n_idx, n_chans, int(bandwidth)))
+        if nbytes == 0:
+            raise ValueError("bad shape for the fit objective")
+        buf = workspace.get(nbytes, y.device)
+        cap, bcap = 4096, 512
+        hx, hf = np.empty(cap, dtype=np.float64), np.empty(cap, dtype=np.float64)
+        sizes = np.empty(bcap, dtype=np.int32)
+        nb = C.c_int32(0)
+        with torch.cuda.device(y.device):
+            check(lib().parrm_nm_minimise_fit(self._h, y.data_ptr(), y.stride(0), idx.data_ptr(), n_idx, n_chans, int(bandwidth),
+                                              float(lambda_), buf.data_ptr(), nbytes, _stream_ptr(torch), hx.ctypes.data,
+                                              hf.ctypes.data, cap, sizes.ctypes.data, bcap, C.byref(nb)),
+                  "parrm_nm_minimise_fit")
+        log, at = [], 0
+        for k in range(nb.value):
+            n = int(sizes[k])
+            log.append((hx[at:at + n].copy(), hf[at:at + n].copy()))
+            at += n
+        return self.results(), log
 
 
 def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, workspace: FitWorkspace | None = None,

@@ -50,6 +50,7 @@ _STAGE_BANDWIDTHS = (5, 10, 20)
 _STAGE_LAMBDA = 1.0
 # stage grids up to this many candidates join the optimiser steps in find_period_batched's shared call
 _SMALL_GRID = 512
+_NM_IN_PYTHON = __import__("os").environ.get("PARRM_NM_PYTHON", "0") == "1"  # step through _neldermead.py (A/B, debugging)
 # above this size a host recording is streamed through the device instead of cached on it
 _DEVICE_CACHE_BYTES = 96 << 30
 _HALF_WIDTH_MEMO: dict = {}  # (limit, omit, period, period half-width) -> default filter half-width
@@ -447,6 +448,13 @@ class PARRM:
         """Evaluate one request of this object's own search."""
         if request.is_grid:
             return self._grid_errors(request.y, request.d_idx, request.periods, request.bandwidth, workspace)
+        if isinstance(request, NelderMeadRequest):
+            # the whole refinement inside the library: no Python between two optimiser batches (PARRM_NM_PYTHON=1
+            # steps through pyparrm_amd/_neldermead.py instead: same batches, same decisions)
+            if _NM_IN_PYTHON:
+                return None
+            return _hip.NativeNelderMead(request.starts).minimise_fit(request.y, request.d_idx, request.bandwidth,
+                                                                     request.lambda_, workspace)
         return _hip.fit_errors(request.y, request.d_idx, request.periods, request.bandwidth, request.lambda_, workspace)
 
     def _optimise_period_estimate(self) -> None:
@@ -849,9 +857,27 @@ class FitRequest:
         self.bandwidth, self.lambda_, self.is_grid = bandwidth, lambda_, is_grid
 
 
+class NelderMeadRequest:
+    """A whole lock-step Nelder-Mead refinement (parrm.py:510-517, :545-550) offered to the driver in one piece: a
+    driver that can run it natively (``PARRM._answer``: one C call, ``parrm_nm_minimise_fit``) sends back
+    ``(results, log)``; one that cannot -- the batched driver, which merges the steps of several searches --
+    sends back ``None`` and gets the same refinement as a sequence of :class:`FitRequest` steps."""
+
+    __slots__ = ("starts", "y", "d_idx", "bandwidth", "lambda_")
+    is_grid = False
+
+    def __init__(self, starts, y, d_idx, bandwidth, lambda_):
+        self.starts, self.y, self.d_idx, self.bandwidth, self.lambda_ = starts, y, d_idx, bandwidth, lambda_
+
+
 def _fmin_requests(starts, y, d_idx, bandwidth, lambda_, log):
     """Lock-step Nelder-Mead from ``starts`` as a generator of :class:`FitRequest` (one per optimiser
     step); returns ``fmin_lockstep``'s result list.  Every evaluation is appended to ``log``."""
+    whole = yield NelderMeadRequest([float(x) for x in starts], y, d_idx, bandwidth, lambda_)
+    if whole is not None:
+        results, evals = whole
+        log.extend(evals)
+        return results
     steps = fmin_lockstep_requests(starts)
     try:
         points = next(steps)
@@ -909,6 +935,14 @@ def find_period_batched(parrms, search_samples=None, assumed_periods=None, outli
             searches.append(search)
             pending.append(next(search))
             spaces.append(_hip.FitWorkspace())
+
+        def advance(search, answer):
+            """Next FitRequest of a search (whole-refinement offers are declined: the steps of all searches are merged)."""
+            request = search.send(answer)
+            while isinstance(request, NelderMeadRequest):
+                request = search.send(None)
+            return request
+
         active = list(range(len(parrms)))
         while active:
             answers = {}
@@ -927,7 +961,7 @@ def find_period_batched(parrms, search_samples=None, assumed_periods=None, outli
             still = []
             for i in active:
                 try:
-                    pending[i] = searches[i].send(answers[i])
+                    pending[i] = advance(searches[i], answers[i])
                     still.append(i)
                 except StopIteration:
                     pass

@@ -73,3 +73,54 @@ def test_maxfun_termination_matches_scipy():
     ref = fmin(lambda x: float(f(x[0])), 0.4, full_output=True, disp=False, maxfun=11)
     got = fmin_lockstep(lambda xs: np.array([f(x) for x in xs]), [0.4], maxfun=11, maxiter=np.inf)[0]
     assert got[0][0] == ref[0][0] and got[1] == ref[1] and got[3] == ref[3]
+
+
+def test_native_neldermead_equals_the_python_generator():
+    """csrc/parrm_nm.hip (the refinement inside the C library: ``parrm_nm_next`` / ``parrm_nm_feed``, and through them
+    ``parrm_nm_minimise_fit``) against ``fmin_lockstep_requests``: the same batches of abscissae in the same order and
+    the same (xopt, fopt, iterations, funcalls) on 400 random problems -- smooth, rough, NaN plateaus, runs that end on
+    maxiter / maxfun, exact ties, a zero start, one to five starts, random tolerances.  Needs no GPU."""
+    from pyparrm_amd import _hip
+    from pyparrm_amd._neldermead import fmin_lockstep_requests
+
+    rng = np.random.default_rng(0)
+
+    def objective(kind, c):
+        if kind == 0:
+            return lambda x: (x - c) ** 2 * 1e-3 + 1.0 + 1e-4 * np.sin(40 * x)
+        if kind == 1:
+            return lambda x: np.abs(x - c) ** 1.5 + 0.3 * np.cos(7 * x)
+        if kind == 2:
+            return lambda x: np.where(np.abs(x - c) < 0.3, np.nan, (x - c) ** 2)  # a NaN plateau
+        if kind == 3:
+            return lambda x: -np.exp(-((x - c) ** 2)) + 1e-2 * x  # flat far out: runs into maxfun
+        return lambda x: np.floor(5 * (x - c)) ** 2 + 0.0  # plateaus: exact ties
+
+    batches = 0
+    for case in range(400):
+        c = rng.uniform(-5, 200)
+        f = objective(case % 5, c)
+        n = int(rng.integers(1, 6))
+        starts = list(c + rng.uniform(-3, 3, n)) if case % 7 else [0.0] + list(c + rng.uniform(-1, 1, n - 1))
+        kw = dict(xtol=10.0 ** rng.integers(-6, -2), ftol=10.0 ** rng.integers(-6, -2))
+        if case % 11 == 0:
+            kw.update(maxiter=int(rng.integers(1, 30)), maxfun=int(rng.integers(2, 40)))
+        steps = fmin_lockstep_requests(starts, kw["xtol"], kw["ftol"], kw.get("maxiter"), kw.get("maxfun"))
+        native = _hip.NativeNelderMead(starts, **kw)
+        try:
+            points = next(steps)
+            while True:
+                mine = native.next_batch()
+                assert mine is not None and np.array_equal(mine, points), (case, points, mine)
+                values = np.asarray(f(points), dtype=np.float64)
+                native.feed(values)
+                batches += 1
+                points = steps.send(values)
+        except StopIteration as stop:
+            expected = stop.value
+        assert native.next_batch() is None, case
+        for a, b in zip(expected, native.results()):
+            assert np.array_equal(a[0], b[0], equal_nan=True), case
+            assert a[1] == b[1] or (a[1] != a[1] and b[1] != b[1]), case
+            assert a[2:] == b[2:], case
+    assert batches > 3000

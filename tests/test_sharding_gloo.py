@@ -128,6 +128,7 @@ def _install_oracle_device(torch, orc):
     _hip.gather_standardise = gather
     _hip.fit_errors = fit_errors
     _hip.FitWorkspace = lambda: None
+    facade._NM_IN_PYTHON = True  # the refinement step by step through the stand-in objective (not the library's own loop)
     _hip.FilterPlan = Plan
     _hip.to_host_numpy = lambda t: t.numpy()
     _hip.upload_indices = lambda indices, device: torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64))
