@@ -677,6 +677,9 @@ class FitWorkspace:
         return self._h_per, self._h_err, self._d_per, self._d_err
 
 
+_NM_WORKSPACE_BYTES: dict = {}
+
+
 class NativeNelderMead:
     """The lock-step Nelder-Mead of ``pyparrm_amd/_neldermead.py`` in the C library (``csrc/parrm_nm.hip``): the same
     batches, the same decisions.  Step interface (``next_batch`` / ``feed``: needs no GPU -- tests drive it against
@@ -725,7 +728,10 @@ class NativeNelderMead:
         (device tensors); returns ``(results, log)`` with ``log`` the list of ``(points, errors)`` per batch."""
         torch = require_gpu()
         n_idx, n_chans = (int(v) for v in y.shape)
-        nbytes = int(lib().parrm_nm_fit_workspace_bytes(n_idx, n_chans, int(bandwidth)))
+        key = (n_idx, n_chans, int(bandwidth))
+        nbytes = _NM_WORKSPACE_BYTES.get(key)
+        if nbytes is None:  # (the library scans every batch size up to 64 for the largest scratch: once per shape)
+            nbytes = _NM_WORKSPACE_BYTES[key] = int(lib().parrm_nm_fit_workspace_bytes(n_idx, n_chans, int(bandwidth)))
         if nbytes == 0:
             raise ValueError("bad shape for the fit objective")
         buf = workspace.get(nbytes, y.device)

@@ -420,10 +420,13 @@ class PARRM:
         ):
             indices = self._get_centre_indices(use_n, ignore, rng)
             plans.append((run, indices, int(np.min((bandwidth, indices.shape[0] // 4)))))
+        # (so is the first stage's candidate grid -- it depends on the assumed periods only --: built before the index
+        # upload below blocks on the statistics pass, not in the gap between the gathers and the first grid's kernels)
+        first_grid = self._get_possible_periods(estimate, 1)
         matrices = [self._stage_matrix(indices) for _, indices, _ in plans]
         for (run, indices, bandwidth), (y, d_idx) in zip(plans, matrices):
             stage = (y, d_idx)
-            grid = self._get_possible_periods(estimate, run)
+            grid = first_grid if run == 1 else self._get_possible_periods(estimate, run)
             errors = yield FitRequest(y, d_idx, grid, bandwidth, _STAGE_LAMBDA, True)
             ranked, ranked_errors = _rank_candidates(grid, errors)
             evals = []
