@@ -937,3 +937,30 @@ def test_packed_three_row_gram_form_equals_the_full_product(monkeypatch, n_chans
     rows = np.ascontiguousarray(y.cpu().numpy().T)
     ref = np.array([orc.fit_error_gathered(p, rows, n_chans, idx.cpu().numpy(), 20, 1.0) for p in periods[:3]])
     np.testing.assert_allclose(whole[:3], ref, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_refinement_inside_the_library_equals_the_python_stepping(monkeypatch):
+    """``parrm_nm_minimise_fit`` (the whole Nelder-Mead refinement of a stage in one C call, csrc/parrm_nm.hip) against
+    the same refinement stepped through ``pyparrm_amd/_neldermead.py`` (``PARRM_NM_PYTHON=1``'s path): the same batches
+    of abscissae with the same errors, stage by stage and in the final polish, and so the same period -- on a
+    multi-channel recording with five starts per stage and on a short single-channel one."""
+    from pyparrm_amd import parrm as facade
+
+    for n_chans, n_samples, seed in ((6, 400_000, 3), (1, 60_000, 4)):
+        x = synth_recording_exact(n_chans, n_samples, 22000.0 / 130.0 * (1 + 2e-4), seed)
+        traces = []
+        for in_python in (False, True):
+            monkeypatch.setattr(facade, "_NM_IN_PYTHON", in_python)
+            p = PARRM(x, 22000.0, 130.0, verbose=False)
+            p.find_period(random_seed=9)
+            traces.append((p.period, p._trace))
+        (period_a, trace_a), (period_b, trace_b) = traces
+        assert period_a == period_b
+        for ta, tb in zip(trace_a, trace_b):
+            for key in ("refine_evals", "final_evals"):
+                if key not in ta:
+                    continue
+                assert len(ta[key]) == len(tb[key]) > 0, key
+                for (pa, ea), (pb, eb) in zip(ta[key], tb[key]):
+                    assert np.array_equal(pa, pb) and np.array_equal(ea, eb), key
