@@ -518,6 +518,24 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             for (int k = 0; k < NS; ++k) asm volatile("" : "+v"(qs[d][k]));
         }
     };
+    auto pin_accumulators = [&]() {
+        // every accumulator in the accumulation registers at the loop's entry and back edge: in the narrow forms hipcc
+        // kept some of them in vector registers there and moved up to 80 dwords in and out every iteration
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) asm volatile("" : "+a"(acc[rt][t]));
+        if constexpr (GM == 2) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) asm volatile("" : "+a"(gsp[k]));
+        } else {
+#pragma unroll
+            for (int gr = 0; gr < NG; ++gr)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) asm volatile("" : "+a"(gacc[gr][ct]));
+        }
+    };
+    pin_accumulators();
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(d);
     for (int u = u_lo; u < u_hi; u += D) {  // the slice is whole 16-sample tiles: a multiple of D steps
@@ -586,6 +604,7 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             fetch(d);
             __builtin_amdgcn_sched_barrier(0);
         }
+        pin_accumulators();
     }
     // The requests past the slice's end are still in flight here and the compiler does not know: it would compute the
     // epilogue's addresses in their destination registers (dead, to its knowledge) and a late return would overwrite
