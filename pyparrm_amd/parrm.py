@@ -497,10 +497,9 @@ class PARRM:
                 1 + np.arange(-1e-3, 1e-3 + 1e-5, 1e-5) / run,
             )
         )
-        candidates = []
-        for estimate in estimated_period:
-            candidates.extend(estimate * rel)
-        return np.unique(candidates)
+        # (every estimate times every factor: the products of the reference's loop, as one outer product)
+        estimates = np.asarray(estimated_period, dtype=np.float64).reshape(-1)
+        return np.unique(np.multiply.outer(estimates, rel))
 
     # ------------------------------------------------------------------ explorer (out of scope)
     def explore_filter_params(self, time_range=None, time_res=0.01, freq_range=None, freq_res=5.0,
