@@ -1312,23 +1312,40 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw, 
     const int64_t groups = stacks(n_periods, g.packed);  // workgroups per sample slice
     const int64_t plan_groups = plan_periods > n_periods ? stacks(plan_periods, g.packed) : groups;
     g.groups = static_cast<int>(groups);
-    // Sample slices per candidate group.  512 workgroups are resident at once (2 per CU), so the run
-    // time is ~ceil(workgroups / 512) rounds of (work per workgroup ~ 1/nsplit): pick the nsplit
-    // that minimises rounds/nsplit (e.g. 381 candidates: nsplit 2 -> 762 workgroups = 2 rounds,
-    // nsplit 4 -> 1524 = 3 rounds of half the length).  Each extra slice costs a 125 KB partial block
-    // for fit_reduce_kernel, hence the small per-slice penalty; never below 4 tiles per slice.
+    // Sample slices per candidate group.  512 workgroups are resident at once (2 per CU), so the Gram kernel takes
+    // ~ceil(workgroups / 512) rounds of (time of a whole-length workgroup / nsplit): e.g. 381 candidates in 326
+    // stacks: nsplit 3 -> 978 workgroups = 2 rounds of a third each.  Slicing is not free: every slice leaves a
+    // partial block per candidate (33 / 64 / 125 KB at K = 11 / 21 / 41) that the Gram kernel writes and
+    // fit_reduce_kernel reads and adds -- ~2.5 transfers of it at ~5 TB/s; at 10 044 candidates two slices cost
+    // 0.33 ms, more than the half round they save (measured: 5.28 ms with two slices, 5.05 ms with one).  Both in
+    // microseconds: a whole-length workgroup takes ~0.2 us per sample at 12 MFMAs per wave and step (256 columns;
+    // the one-wave forms for <= 16 / <= 32 columns a quarter / half of that).  Never below 4 tiles per slice.
     const int64_t max_split = std::max<int64_t>(1, std::min<int64_t>(64, (tiles + 3) / 4));
     const int64_t resident = n_chans <= 64 ? 1024 : 512;  // one-wave workgroups (<= 64 channels): four per CU
+    const double t_full = 0.2 * static_cast<double>(g.n_pad) * (n_chans <= 16 ? 0.25 : (n_chans <= 32 ? 0.5 : 1.0));
+    const int64_t plan_p = std::max(plan_periods, n_periods);
+    const double cols_used = static_cast<double>(std::min<int64_t>(n_chans, kYCols) + 64);
+    const double slice_us = static_cast<double>(plan_p) * g.nz * (g.KP + 1) * cols_used * 8.0 * 2.5 / 5.0e6;
     double best = 1e300;
     g.nsplit = 1;
     for (int64_t ns = 1; ns <= max_split; ++ns) {
-        const int64_t rounds = (plan_groups * g.nz * ns + resident - 1) / resident;
-        const double cost = static_cast<double>(rounds) / static_cast<double>(ns) * (1.0 + 0.004 * ns);
-        if (cost < best - 1e-12) {
+        // (a last round that fills at most half the slots runs one workgroup per CU, with the matrix pipes to itself:
+        // measured ~0.55 of a full round)
+        const int64_t wgs = plan_groups * g.nz * ns, tail = wgs % resident;
+        const double rounds = static_cast<double>(wgs / resident) + (tail == 0 ? 0.0 : (tail <= resident / 2 ? 0.55 : 1.0));
+        // (grids below 2048 candidates keep round 2's rule -- whole rounds, a 0.4 % penalty per slice: their splits
+        // differ little either way, and the sum order they imply is the one the 70 reference periods were matched
+        // bit for bit with; one of them moves by an ulp under the other rule's splits)
+        const double cost = plan_p >= 2048
+                                ? rounds / static_cast<double>(ns) * t_full + (ns > 1 ? slice_us * ns : 0.0)
+                                : static_cast<double>((wgs + resident - 1) / resident) / static_cast<double>(ns) * (1.0 + 0.004 * ns);
+        if (cost < best - 1e-9) {
             best = cost;
             g.nsplit = static_cast<int>(ns);
         }
     }
+    if (const char *force = getenv("PARRM_FIT_X_NSPLIT"))  // (timing experiment)
+        g.nsplit = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(max_split, atoi(force))));
     g.elems = static_cast<int64_t>(g.KP + 1) * kNCol;
     // whole 48-row stacks (room for the padded layout too: operands the matrix cores cannot take fall back to it)
     g.w_bytes = static_cast<size_t>(std::max(groups, stacks(n_periods, false))) * 48 * g.n_pad * sizeof(double);

@@ -10,8 +10,8 @@ from pyparrm_amd import _hip
 _hip.require_gpu()
 C = 256
 g = torch.Generator(device="cuda").manual_seed(1)
-shapes = [(10044, 5001, 5), (387, 10001, 10), (381, 24963, 20), (9, 24963, 20)]
-arms = [{}] + [{"PARRM_FIT_X_NOGRAM": "1"}] + [{"PARRM_FIT_X_NSPLIT": str(k)} for k in (1, 2, 3, 4, 6, 8, 16)]
+shapes = [(10044, 5001, 5), (381, 24963, 20), (9, 24963, 20), (4, 24963, 20), (12, 5001, 5), (10, 10001, 10)]
+arms = [{}] + [{"PARRM_FIT_X_NSPLIT": str(k)} for k in (1, 2, 3, 32, 48, 64)]
 for P, n, bw in shapes:
     y = torch.randn((n, C), generator=g, device="cuda", dtype=torch.float64).clamp_(-3, 3)
     idx = torch.arange(1000, 1000 + n, device="cuda", dtype=torch.int64)

@@ -454,7 +454,9 @@ def test_find_period_batched_amortises_the_optimiser_steps():
     t2 = time.perf_counter()
     assert a == b
     print(f"\n8 sites: sequential {1e3 * (t1 - t0):.1f} ms, batched {1e3 * (t2 - t1):.1f} ms")
-    assert t2 - t1 < 0.8 * (t1 - t0)
+    # (round 3 moved a single search's refinement into the library -- no Python between its optimiser batches -- so the
+    # one-by-one baseline got ~25 % faster and the batched form's margin is what the shared kernels still save)
+    assert t2 - t1 < 0.95 * (t1 - t0)
 
 
 # ---------------------------------------------------------------------------- ingestion + online mode (f4)
