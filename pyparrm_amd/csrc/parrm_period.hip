@@ -477,32 +477,32 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     const u4_t dw = desc_of(Ws + static_cast<int64_t>(pb) * n_pad * KS, n_pad * KS * 8);
     const u4_t dsp = desc_of(Ws + static_cast<int64_t>(s_base) * n_pad * KS,
                              GM == 2 ? min(3, n_stacks - s_base) * n_pad * KS * 8 : 0);
-    u4_t qy[D][NYL];                          // data: CT = 4 two quads of 16 bytes, CT = 2 one
-    u2_t qy1[D];                              // data, CT = 1: one column
+    u4_t qy[D][NYL];                          // data: CT = 4 two quads of 16 bytes, CT = 2 one; CT = 1: .x/.y only
     u2_t qa[D][3], qs[D][NS == 0 ? 1 : NS];   // design rows of the three row tiles; special rows
-    // the requests advance through SCALAR offsets (one s_add per stream and step instead of a vector add per address):
-    // the per-lane offsets stay as computed above; a lane without a data column keeps its out-of-range sentinel (the
-    // scalar offset added to 0x80000000 is still beyond every buffer)
-    unsigned so_y = 0, so_w = 0;
     auto fetch = [&](int d) {
         if constexpr (CT == 4) {
-            asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
-                         : "=&v"(qy[d][0]), "=&v"(qy[d][1]) : "v"(vy), "s"(dy), "s"(so_y) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16"
+                         : "=&v"(qy[d][0]), "=&v"(qy[d][1]) : "v"(vy), "s"(dy) : "memory");
         } else if constexpr (CT == 2) {
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(qy[d][0]) : "v"(vy), "s"(dy), "s"(so_y) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(qy[d][0]) : "v"(vy), "s"(dy) : "memory");
         } else {
-            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(qy1[d]) : "v"(vy), "s"(dy), "s"(so_y) : "memory");
+            u2_t one;
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(one) : "v"(vy), "s"(dy) : "memory");
+            qy[d][0].x = one.x;
+            qy[d][0].y = one.y;
         }
-        asm volatile("buffer_load_dwordx2 %0, %3, %4, %5 offen\n\tbuffer_load_dwordx2 %1, %3, %4, %5 offen offset:128\n\t"
-                     "buffer_load_dwordx2 %2, %3, %4, %5 offen offset:256"
-                     : "=&v"(qa[d][0]), "=&v"(qa[d][1]), "=&v"(qa[d][2]) : "v"(vw), "s"(dw), "s"(so_w) : "memory");
+        asm volatile("buffer_load_dwordx2 %0, %3, %4, 0 offen\n\tbuffer_load_dwordx2 %1, %3, %4, 0 offen offset:128\n\t"
+                     "buffer_load_dwordx2 %2, %3, %4, 0 offen offset:256"
+                     : "=&v"(qa[d][0]), "=&v"(qa[d][1]), "=&v"(qa[d][2]) : "v"(vw), "s"(dw) : "memory");
         if constexpr (GM == 2) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k)
-                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(qs[d][k]) : "v"(vs[k]), "s"(dsp), "s"(so_w) : "memory");
+            for (int k = 0; k < NS; ++k) {
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(qs[d][k]) : "v"(vs[k]), "s"(dsp) : "memory");
+                vs[k] += step_w;
+            }
         }
-        so_y += step_y;
-        so_w += step_w;
+        if (col_ok) vy += step_y;
+        vw += step_w;
     };
     // the step's operands have landed once at most the three younger steps' requests are outstanding; the "+v" ties
     // make every use of them depend on this wait
@@ -510,11 +510,8 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
         if constexpr (CT == 4)
             asm volatile("s_waitcnt vmcnt(%5)" : "+v"(qy[d][0]), "+v"(qy[d][1]), "+v"(qa[d][0]), "+v"(qa[d][1]), "+v"(qa[d][2])
                          : "n"(3 * LPS) : "memory");
-        else if constexpr (CT == 2)
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qy[d][0]), "+v"(qa[d][0]), "+v"(qa[d][1]), "+v"(qa[d][2])
-                         : "n"(3 * LPS) : "memory");
         else
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qy1[d]), "+v"(qa[d][0]), "+v"(qa[d][1]), "+v"(qa[d][2])
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qy[d][0]), "+v"(qa[d][0]), "+v"(qa[d][1]), "+v"(qa[d][2])
                          : "n"(3 * LPS) : "memory");
         if constexpr (GM == 2) {
 #pragma unroll
@@ -549,11 +546,8 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
             double a[3], y[CT];
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt) a[rt] = __builtin_bit_cast(double, qa[d][rt]);
-            if constexpr (CT == 1) y[0] = __builtin_bit_cast(double, qy1[d]);
-            if constexpr (CT >= 2) {
-                y[0] = __builtin_bit_cast(double, u2_t{qy[d][0].x, qy[d][0].y});
-                y[1] = __builtin_bit_cast(double, u2_t{qy[d][0].z, qy[d][0].w});
-            }
+            y[0] = __builtin_bit_cast(double, u2_t{qy[d][0].x, qy[d][0].y});
+            if constexpr (CT >= 2) y[1] = __builtin_bit_cast(double, u2_t{qy[d][0].z, qy[d][0].w});
             if constexpr (CT == 4) {
                 y[2] = __builtin_bit_cast(double, u2_t{qy[d][1].x, qy[d][1].y});
                 y[3] = __builtin_bit_cast(double, u2_t{qy[d][1].z, qy[d][1].w});
@@ -621,12 +615,8 @@ __device__ __forceinline__ void fit_accum_mfma_body(const double *Y, int64_t ldy
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        if constexpr (CT == 1) {
-            asm volatile("" : "+v"(qy1[d]));
-        } else {
 #pragma unroll
-            for (int k = 0; k < NYL; ++k) asm volatile("" : "+v"(qy[d][k]));
-        }
+        for (int k = 0; k < NYL; ++k) asm volatile("" : "+v"(qy[d][k]));
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt) asm volatile("" : "+v"(qa[d][rt]));
         if constexpr (GM == 2) {
