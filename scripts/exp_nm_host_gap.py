@@ -2,6 +2,7 @@
 """Where do the ~27 us between two optimiser batches go?  Times the C call of every small batch and the Python time
 between two calls (Nelder-Mead bookkeeping, request plumbing)."""
 import os, sys, time
+os.environ.setdefault("PARRM_NM_PYTHON", "1")  # (the refinement stepped from Python: inside the library there is no call to time)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -35,6 +35,12 @@ def wrapped(y, idx, periods, bw, lam, ws=None, grid_periods=0):
 
 
 _hip.fit_errors = wrapped
+# (the per-batch split needs the refinement stepped from Python: inside the library -- the default, timed above -- there
+# is no call per batch to wrap; the stepped form costs ~13 us more host time per batch)
+from pyparrm_amd import parrm as _facade
+
+_facade._NM_IN_PYTHON = True
+print("instrumented pass: refinement stepped from Python (PARRM_NM_PYTHON=1's path)")
 import pyparrm_amd.parrm as pm
 
 pm._hip.fit_errors = wrapped
