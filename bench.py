@@ -493,7 +493,7 @@ def main():
             per_step_ms = float(np.mean([sum(g[0] for g in gs) for gs in timings["grids"]]))
             flops = float(np.mean([sum(g[1] for g in gs) for gs in timings["grids"]]))
             out["roofline_find_period"] = {
-                "kernel": "fit_accum_mfma_kernel (bracket = one grid call: design matrices, Gram blocks, reduction, solves)",
+                "kernel": "fit_accum_fused_kernel (bracket = one grid call: design rows + Gram blocks in one kernel, reduction, solves)",
                 "bound": "fp64-mfma", "flops": flops, "ms_per_step": per_step_ms,
                 "achieved": flops / per_step_ms / 1e9, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / per_step_ms / 1e9 / 78.6,
                 "grids": [{"candidates": g[2], "K": g[3], "ms": g[0]} for g in timings["grids"][-1]],

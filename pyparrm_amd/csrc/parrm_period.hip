@@ -700,6 +700,257 @@ __global__ void __launch_bounds__(256) fit_accum_mfma_kernel(const double *Y, in
     fit_accum_mfma_body<NW, CT, GM>(Y, ldy, Ws, n_pad, n_idx, n_chans, n_periods, kpc, nsplit, part, this_block(), kreal);
 }
 
+// FUSED form of the packed / special-rows Gram kernel (round 3, 256-channel blocks): the design rows are not read from
+// memory -- the workgroup computes them itself, 64 samples at a time, into an LDS tile (the arithmetic of
+// fit_trig_packed_body statement for statement: one sincos per candidate and sample, the recurrence for the harmonics),
+// while the matrix cores work on the previous tile.  The MFMA operands are the same values in the same order as in
+// fit_accum_mfma_body<4, 4, 2>, so the partial blocks are its bits; what goes away is the design-matrix kernel (its
+// 4.4 GB of writes at the 10 044-candidate grid, 0.7 ms; 20 us + a launch in front of every optimiser batch) and the
+// Gram kernel's operand traffic for it.
+//  * LDS tile: row = sample (64), FS = 67 doubles per row: the stack's 48 design rows, then rows 0, K-2, K-1 of each of
+//    the <= 6 candidates with rows in the stack (the special A operand: a straddling candidate's rows are computed
+//    here rather than fetched from the neighbouring stack), then one zero.  Two tiles (68.6 KB): wave q computes
+//    candidates q, q + 4 of tile i + 1 right after the barrier that opens tile i.
+//  * One barrier per tile (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would also drain the data requests).
+//  * The sample indices of tile i + 2 are requested (one buffer load per lane) when tile i opens, in the same counted
+//    queue as the data quads; every data wait keeps the 3-steps-younger rule, which with the index request in the queue
+//    waits for at most one request more than needed.
+constexpr int kFusedRow = 67, kFusedTile = 64 * kFusedRow;                    // doubles
+constexpr int kFusedLdsBytes = (2 * kFusedTile + 4 * kFusedRow) * 8;          // (+ the rows the last look-ahead read touches)
+__device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ldy, const int64_t *idx, const double *periods,
+                                                     int n_pad, int n_idx, int n_chans, int n_periods, int kpc, int nsplit,
+                                                     double *part, const Blk blk, int K) {
+    extern __shared__ double fused_lds[];
+    constexpr int KS = 48, D = 4, CT = 4, FS = kFusedRow;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, sj = lane >> 4;
+    const int sl = blk.x, pb = blk.y, zb = blk.z, nz = blk.nz;
+    const int tiles = n_pad / kTJ;
+    const int per = (tiles + nsplit - 1) / nsplit;
+    const int u_lo = sl * per * 4;  // steps of 4 samples
+    const int u_hi = min(tiles, sl * per + per) * 4;
+    const int col0 = 64 * wv + 4 * c;
+    const bool col_ok = zb * kYCols + col0 < n_chans;
+    const unsigned step_y = static_cast<unsigned>(4 * ldy * 8);
+    unsigned vy = col_ok ? static_cast<unsigned>(((static_cast<int64_t>(u_lo) * 4 + sj) * ldy + col0) * 8) : 0x80000000u;
+    const int g0 = KS * pb, p0 = g0 / K;
+    const int n_cand = (KS + K - 2) / K + 1;  // packed_trig_waves(K)
+    // the special operand of this wave's column tile (tile min(wave, 2)): lane c reads special row c % 3 of the
+    // (c / 3)-th candidate that owns columns of the tile, or the zero
+    const int gl = g0 + 16 * min(wv, 2);
+    int spcol;
+    {
+        const int ci = c / 3, t = c - 3 * ci, pc = gl / K + ci;
+        const bool own = pc <= (gl + 15) / K && pc < n_periods;
+        spcol = own ? KS + 3 * (pc - p0) + t : FS - 1;
+    }
+    for (int e = tid; e < 2 * 64 + 4; e += 256) fused_lds[e * FS + FS - 1] = 0.0;
+    // the <= 2 candidates whose rows this wave computes
+    // (two scalars, not an array: indexed by the loop below it would live in scratch, and every scratch read drains the
+    // request queue)
+    const double w0a = p0 + wv < n_periods ? 6.283185307179586 / periods[p0 + wv] : 0.0;  // (2 * np.pi / period)
+    const double w0b = wv + 4 < n_cand && p0 + wv + 4 < n_periods ? 6.283185307179586 / periods[p0 + wv + 4] : 0.0;
+
+    d4_t acc[3][CT], gsp;
+    double yy[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) yy[t] = 0.0;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = d4_t{0.0, 0.0, 0.0, 0.0};
+    gsp = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    constexpr int LPS = 2;  // requests per step: the two data quads
+    auto desc_of = [](const void *base, int bytes) -> u4_t {
+        const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+        return u4_t{static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(p))),
+                    static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(p >> 32))) & 0xffffu,
+                    static_cast<unsigned>(__builtin_amdgcn_readfirstlane(bytes)), 0x00020000u};
+    };
+    const u4_t dy = desc_of(Y + static_cast<int64_t>(zb) * kYCols,
+                            static_cast<int>((static_cast<int64_t>(n_idx) * ldy - static_cast<int64_t>(zb) * kYCols) * 8));
+    const u4_t di = desc_of(idx, n_idx * 8);  // (beyond the last index: zeros, and the rows are zeros then)
+    u4_t qy[D][2];
+    u2_t qi;
+    unsigned vi = static_cast<unsigned>((u_lo * 4 + lane) * 8);  // this lane's sample of the tile whose indices come next
+    auto fetch = [&](int d) {
+        asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16"
+                     : "=&v"(qy[d][0]), "=&v"(qy[d][1]) : "v"(vy), "s"(dy) : "memory");
+        if (col_ok) vy += step_y;
+    };
+    auto fetch_indices = [&]() {
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(qi) : "v"(vi), "s"(di) : "memory");
+        vi += 64 * 8;
+    };
+    auto landed = [&](int d) {
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(qy[d][0]), "+v"(qy[d][1]) : "n"(3 * LPS) : "memory");
+    };
+    auto pin_accumulators = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) asm volatile("" : "+a"(acc[rt][t]));
+        asm volatile("" : "+a"(gsp));
+    };
+    // design rows of the 64 samples from `j0` on into `tile` (this wave's candidates; `qi` holds the lane's index)
+    auto design_rows = [&](int j0, double *tile) {
+        const int j = j0 + lane;
+        const int64_t at = static_cast<int64_t>((static_cast<unsigned long long>(qi.y) << 32) | qi.x);
+        auto candidate = [&](int q, double w0) {
+            const int p = p0 + q;
+            const int k_lo = max(g0 - p * K, 0), k_hi = min(g0 + KS - p * K, K);  // its rows [k_lo, k_hi) lie in the stack
+            if (k_lo >= k_hi) return;                     // (the last of the <= n_cand may begin beyond the stack)
+            double *t = tile + lane * FS + (p * K - g0);  // t[k] = row k of the candidate (k_lo <= k < k_hi)
+            double *sp = tile + lane * FS + KS + 3 * q;   // its rows 0, K-2, K-1
+            if (j >= n_idx || p >= n_periods) {
+                for (int k = k_lo; k < k_hi; ++k) t[k] = 0.0;
+                sp[0] = 0.0;
+                sp[1] = 0.0;
+                sp[2] = 0.0;
+            } else {
+                const double ang = static_cast<double>(at + 1) * w0;  // (indices + 1) * ...
+                if (k_lo == 0) t[0] = 1.0;
+                sp[0] = 1.0;
+                double s1, c1;
+                sincos(ang, &s1, &c1);
+                double sk = s1, ck = c1;
+                for (int k = 1; 2 * k < K; ++k) {
+                    if (2 * k - 1 >= k_lo && 2 * k - 1 < k_hi) t[2 * k - 1] = sk;
+                    if (2 * k >= k_lo && 2 * k < k_hi) t[2 * k] = ck;
+                    if (2 * k == K - 1) {
+                        sp[1] = sk;
+                        sp[2] = ck;
+                    }
+                    const double sn = fma(sk, c1, ck * s1);
+                    const double cn = fma(ck, c1, -(sk * s1));
+                    sk = sn;
+                    ck = cn;
+                }
+            }
+        };
+        if (wv < n_cand) candidate(wv, w0a);
+        if (wv + 4 < n_cand) candidate(wv + 4, w0b);
+    };
+
+    // prologue: indices of the first tile, its design rows, the second tile's indices, four steps' data
+    fetch_indices();
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qi) : : "memory");
+    design_rows(u_lo * 4, fused_lds);
+    fetch_indices();
+    pin_accumulators();
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d);
+    const int lane_a = sj * FS + c, lane_s = sj * FS + spcol;
+    const double *cur = fused_lds + kFusedTile;  // (swapped when the first tile opens)
+    double a_nx[3], s_nx;
+    for (int u = u_lo; u < u_hi; u += D) {  // four steps = 16 samples per iteration; a tile every fourth
+        const int g = ((u - u_lo) >> 2) & 3;
+        if (g == 0) {
+            // everyone has left the previous tile (its buffer is free) and has written this one
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            double *nxt = const_cast<double *>(cur);
+            cur = cur == fused_lds ? fused_lds + kFusedTile : fused_lds;
+            // (the index request is older than the four steps' requests in flight)
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qi) : "n"(4 * LPS) : "memory");
+            design_rows(u * 4 + 64, nxt);
+            fetch_indices();
+            pin_accumulators();
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) a_nx[rt] = cur[lane_a + 16 * rt];
+            s_nx = cur[lane_s];
+        }
+        const double *row = cur + (16 * g) * FS;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            landed(d);
+            __builtin_amdgcn_sched_barrier(0);
+            double a[3], y[CT];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) a[rt] = a_nx[rt];
+            const double asp = s_nx;
+            // the next step's design rows (after the tile's last step: rows nobody uses)
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) a_nx[rt] = row[(4 * d + 4) * FS + lane_a + 16 * rt];
+            s_nx = row[(4 * d + 4) * FS + lane_s];
+            __builtin_amdgcn_sched_barrier(0);  // (requested BEFORE this step's products, into registers of their own)
+            y[0] = __builtin_bit_cast(double, u2_t{qy[d][0].x, qy[d][0].y});
+            y[1] = __builtin_bit_cast(double, u2_t{qy[d][0].z, qy[d][0].w});
+            y[2] = __builtin_bit_cast(double, u2_t{qy[d][1].x, qy[d][1].y});
+            y[3] = __builtin_bit_cast(double, u2_t{qy[d][1].z, qy[d][1].w});
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                yy[t] = fma(y[t], y[t], yy[t]);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt)
+                    acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
+            }
+            const double bw_ = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
+            gsp = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, bw_, gsp, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(d);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pin_accumulators();
+    }
+    // (requests past the slice's end are still in flight: see fit_accum_mfma_body)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        asm volatile("" : "+v"(qy[d][0]));
+        asm volatile("" : "+v"(qy[d][1]));
+    }
+    asm volatile("" : "+v"(qi));
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        yy[t] += __shfl_xor(yy[t], 16);
+        yy[t] += __shfl_xor(yy[t], 32);
+    }
+    auto block_of = [&](int pc) -> double * {
+        return part + ((static_cast<int64_t>(pc) * nz + zb) * nsplit + sl) * static_cast<int64_t>(kpc + 1) * kNCol;
+    };
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 16 * rt + sj + 4 * v;
+            const int pc = (g0 + r) / K, k = g0 + r - pc * K;
+            if (pc >= n_periods) continue;
+            double *out = block_of(pc) + static_cast<int64_t>(k) * kNCol;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) out[col0 + t] = acc[rt][t][v];
+        }
+    }
+    if (wv < 3) {
+        const int g = gl + c, pg = g / K, k = g - pg * K;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = sj + 4 * v, ci = i / 3, t = i - 3 * ci;
+            const int pc = gl / K + ci;
+            if (pc != pg || pc >= n_periods) continue;
+            const int out_row = t == 0 ? 0 : K - 3 + t;
+            block_of(pc)[static_cast<int64_t>(out_row) * kNCol + kYCols + k] = gsp[v];
+        }
+    }
+    if (sj == 0) {
+        const int p_hi = (g0 + KS - 1) / K;
+        for (int pc = p0; pc <= p_hi; ++pc) {
+            if (pc >= n_periods) break;
+            double *out = block_of(pc) + static_cast<int64_t>(kpc) * kNCol;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) out[col0 + t] = yy[t];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) fit_accum_fused_kernel(const SmallPeriods, const double *Y, int64_t ldy,
+                                                               const int64_t *idx, const double *periods, int n_pad,
+                                                               int n_idx, int n_chans, int n_periods, int kpc, int nsplit,
+                                                               double *part, int kreal, int by_value) {
+    fit_accum_fused_body(Y, ldy, idx, by_value ? small_periods_in_kernarg() : periods, n_pad, n_idx, n_chans, n_periods, kpc,
+                         nsplit, part, this_block(), kreal);
+}
+
 // red[(p*nz+zb)][e] = sum_s part[(p*nz+zb)][s][e], s ascending (deterministic)
 // (data columns beyond the recording's channels are never read by the solvers: skipped)
 // (ksp = K when the Gram kernel left only rows 0, K-2, K-1 of W'W -- its GM = 2 form --, else 0)
@@ -1597,7 +1848,15 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
     SmallPeriods small{};
     const int by_value = pub && pub->h_periods && P <= kSmallPeriods;
     if (by_value) std::memcpy(small.p, pub->h_periods, static_cast<size_t>(P) * sizeof(double));
-    if (special) {
+    // 256-channel blocks of the packed form: the Gram kernel computes the design rows itself (fit_accum_fused_body);
+    // PARRM_FIT_UNFUSED=1 keeps the design-matrix kernel + fit_accum_mfma_kernel<4, 4, 2> (same bits)
+    const bool wide = use_mfma && C > 64 && !(C <= 128 && g.nz == 1 && !getenv("PARRM_FIT_NO_TWO_WAVES"));
+    const bool fused = special && wide && !getenv("PARRM_FIT_UNFUSED");
+    if (fused) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(fit_accum_fused_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLdsBytes);
+        PARRM_HIP_CHECK(attr);
+    } else if (special) {
         hipLaunchKernelGGL(fit_trig_packed_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * packed_trig_waves(K)), 0, s,
                            small, d_idx, n, g.n_pad, d_periods, P, bw, exact_trig, wmat, by_value);
     } else if (use_mfma) {
@@ -1619,7 +1878,10 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
             hipLaunchKernelGGL((fit_accum_mfma_kernel<NW_, CT_, 1>), grid, dim3(THREADS_), 0, s, d_y, ldy, wmat, g.n_pad, n, C, \
                                P, g.KP, g.nsplit, part, K);                                                                \
     } while (0)
-    if (use_mfma && C <= 16 && narrow_ok)
+    if (fused)
+        hipLaunchKernelGGL(fit_accum_fused_kernel, grid, dim3(256), kFusedLdsBytes, s, small, d_y, ldy, d_idx, d_periods, g.n_pad,
+                           n, C, P, g.KP, g.nsplit, part, K, by_value);
+    else if (use_mfma && C <= 16 && narrow_ok)
         PARRM_LAUNCH_ACCUM(1, 1, 64);
     else if (use_mfma && C <= 32 && narrow_ok)
         PARRM_LAUNCH_ACCUM(1, 2, 64);

@@ -942,6 +942,39 @@ def test_packed_three_row_gram_form_equals_the_full_product(monkeypatch, n_chans
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_chans", [129, 200, 256, 300, 600])
+def test_fused_gram_kernel_returns_the_two_kernel_forms_bits(monkeypatch, n_chans):
+    """256-channel blocks: the Gram kernel that computes the design rows itself, tile by tile in LDS
+    (``fit_accum_fused_kernel``, the default), against the design-matrix kernel + ``fit_accum_mfma_kernel<4, 4, 2>``
+    (``PARRM_FIT_UNFUSED=1``).  Same operand values in the same order, so ``array_equal``: 1 to 2 stacks' worth of
+    candidates and ragged larger counts, the three bandwidths, sample counts that are not whole 64-sample tiles (so the
+    slices of the sample split end inside a tile), random indices; optimiser-sized batches through the host hand-off
+    (periods by value); slices of a grid."""
+    g = torch.Generator(device="cuda").manual_seed(300 + n_chans)
+    ws, ws_two = _hip.FitWorkspace(), _hip.FitWorkspace()
+    for bw, n in ((5, 1777), (10, 3001), (20, 2500), (20, 24963), (5, 5001)):
+        y = torch.randn((n, (n_chans + 3) // 4 * 4), generator=g, device="cuda", dtype=torch.float64).clamp_(-3, 3)[:, :n_chans]
+        idx = torch.sort(torch.randperm(60000, device="cuda", generator=g)[:n]).values.to(torch.int64)
+        counts = list(range(1, 11)) + [13, 47, 48, 49, 131] if n < 5000 else [1, 4, 9, 70, 381]
+        for n_per in counts:
+            periods = 169.2 * (1 + np.linspace(-2e-2, 2e-2, n_per)) if n_per > 1 else np.array([169.2359])
+            fused = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+            monkeypatch.setenv("PARRM_FIT_UNFUSED", "1")
+            two = _hip.fit_errors(y, idx, periods, bw, 1.0, ws_two)
+            monkeypatch.delenv("PARRM_FIT_UNFUSED")
+            assert np.all(np.isfinite(fused))
+            assert np.array_equal(fused, two), (bw, n, n_per, float(np.max(np.abs(fused - two))))
+        periods = 169.2 * (1 + np.linspace(-2e-2, 2e-2, 131))
+        whole = _hip.fit_errors(y, idx, periods, bw, 1.0, ws)
+        for lo, hi in ((0, 17), (17, 18), (18, 90), (90, 131)):
+            part = _hip.fit_errors(y, idx, periods[lo:hi], bw, 1.0, ws, grid_periods=131)
+            assert np.array_equal(part, whole[lo:hi]), (bw, lo, hi)
+    rows = np.ascontiguousarray(y.cpu().numpy().T)
+    ref = np.array([orc.fit_error_gathered(p, rows, n_chans, idx.cpu().numpy(), 5, 1.0) for p in periods[:2]])
+    np.testing.assert_allclose(whole[:2], ref, rtol=1e-9)
+
+
+@pytest.mark.gpu
 def test_refinement_inside_the_library_equals_the_python_stepping(monkeypatch):
     """``parrm_nm_minimise_fit`` (the whole Nelder-Mead refinement of a stage in one C call, csrc/parrm_nm.hip) against
     the same refinement stepped through ``pyparrm_amd/_neldermead.py`` (``PARRM_NM_PYTHON=1``'s path): the same batches
