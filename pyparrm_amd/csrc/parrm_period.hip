@@ -816,18 +816,39 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
                 double s1, c1;
                 sincos(ang, &s1, &c1);
                 double sk = s1, ck = c1;
-                for (int k = 1; 2 * k < K; ++k) {
-                    if (2 * k - 1 >= k_lo && 2 * k - 1 < k_hi) t[2 * k - 1] = sk;
-                    if (2 * k >= k_lo && 2 * k < k_hi) t[2 * k] = ck;
-                    if (2 * k == K - 1) {
-                        sp[1] = sk;
-                        sp[2] = ck;
-                    }
+                auto next_harmonic = [&]() {
                     const double sn = fma(sk, c1, ck * s1);
                     const double cn = fma(ck, c1, -(sk * s1));
                     sk = sn;
                     ck = cn;
+                };
+                // harmonic k owns rows 2k-1 (sin) and 2k (cos): below the stack's window [k_lo, k_hi) nothing is stored, in
+                // its first and last harmonic perhaps one of the two, between them both, beyond it nothing -- loops without
+                // per-row tests (those cost more than the recurrence: ~25 scalar instructions and three branches a harmonic)
+                const int bw = (K - 1) / 2;
+                const int hf = (max(k_lo, 1) + 1) / 2, hl = k_hi / 2;  // first / last harmonic with a row in the window
+                int k = 1;                                             // (sk, ck) = harmonic k
+                for (; k < hf; ++k) next_harmonic();
+                if (hf <= hl) {
+                    if (2 * k - 1 >= k_lo) t[2 * k - 1] = sk;
+                    if (2 * k < k_hi) t[2 * k] = ck;
+                    if (hl > hf) {
+                        next_harmonic();
+                        ++k;
+                        double *row = t + 2 * k - 1;
+                        for (; k < hl; ++k) {
+                            row[0] = sk;
+                            row[1] = ck;
+                            row += 2;
+                            next_harmonic();
+                        }
+                        t[2 * k - 1] = sk;
+                        if (2 * k < k_hi) t[2 * k] = ck;
+                    }
                 }
+                for (; k < bw; ++k) next_harmonic();
+                sp[1] = sk;
+                sp[2] = ck;
             }
         };
         if (wv < n_cand) candidate(wv, w0a);
