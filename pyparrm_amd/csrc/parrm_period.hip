@@ -780,8 +780,8 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
                      : "=&v"(qy[d][0]), "=&v"(qy[d][1]) : "v"(vy), "s"(dy) : "memory");
         if (col_ok) vy += step_y;
     };
-    auto fetch_indices = [&]() {
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(qi) : "v"(vi), "s"(di) : "memory");
+    auto fetch_indices = [&](u2_t &into) {
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(into) : "v"(vi), "s"(di) : "memory");
         vi += 64 * 8;
     };
     auto landed = [&](int d) {
@@ -795,9 +795,10 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
         asm volatile("" : "+a"(gsp));
     };
     // design rows of the 64 samples from `j0` on into `tile` (this wave's candidates; `qi` holds the lane's index)
-    auto design_rows = [&](int j0, double *tile) {
+    auto design_rows = [&](int j0, double *tile, const u2_t &index) {
         const int j = j0 + lane;
-        const int64_t at = static_cast<int64_t>((static_cast<unsigned long long>(qi.y) << 32) | qi.x);
+        const unsigned index_lo = index.x, index_hi = index.y;  // (components through scalars: see parrm_filter_comb.hip)
+        const int64_t at = static_cast<int64_t>((static_cast<unsigned long long>(index_hi) << 32) | index_lo);
         auto candidate = [&](int q, double w0) {
             const int p = p0 + q;
             const int k_lo = max(g0 - p * K, 0), k_hi = min(g0 + KS - p * K, K);  // its rows [k_lo, k_hi) lie in the stack
@@ -855,14 +856,16 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
         if (wv + 4 < n_cand) candidate(wv + 4, w0b);
     };
 
-    // prologue: indices of the first tile, its design rows, the second tile's indices, four steps' data
-    fetch_indices();
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qi) : : "memory");
-    design_rows(u_lo * 4, fused_lds);
-    fetch_indices();
+    // prologue: the first two tiles' indices, four steps' data (in flight while the first tile's rows are computed)
+    u2_t qi0;
+    fetch_indices(qi0);
+    fetch_indices(qi);
     pin_accumulators();
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(d);
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(qi0), "+v"(qi) : "n"(4 * LPS) : "memory");
+    design_rows(u_lo * 4, fused_lds, qi0);
+    pin_accumulators();
     const int lane_a = sj * FS + c, lane_s = sj * FS + spcol;
     const double *cur = fused_lds + kFusedTile;  // (swapped when the first tile opens)
     double a_nx[3], s_nx;
@@ -875,8 +878,8 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
             cur = cur == fused_lds ? fused_lds + kFusedTile : fused_lds;
             // (the index request is older than the four steps' requests in flight)
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qi) : "n"(4 * LPS) : "memory");
-            design_rows(u * 4 + 64, nxt);
-            fetch_indices();
+            design_rows(u * 4 + 64, nxt, qi);
+            fetch_indices(qi);
             pin_accumulators();
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt) a_nx[rt] = cur[lane_a + 16 * rt];
