@@ -5,9 +5,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_fit
 rm -rf $OUT && mkdir -p $OUT
 for shape in "10044 5001 5 3" "381 24963 20 3" "9 24963 20 40"; do
   set -- $shape
-  for mode in ${MODES:-default full}; do
-    unset PARRM_FIT_FULL_GRAM
+  for mode in ${MODES:-default unfused full}; do  # default = fused Gram kernel; unfused = design-matrix kernel + Gram kernel; full = padded full product
+    unset PARRM_FIT_FULL_GRAM PARRM_FIT_UNFUSED
     [ $mode = full ] && export PARRM_FIT_FULL_GRAM=1
+    [ $mode = unfused ] && export PARRM_FIT_UNFUSED=1
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${1}_$mode -o t -- python3 $GRAFT_REPO_ROOT/scripts/profile_fit.py --periods $1 --n $2 --bw $3 --reps $4 > $OUT/${1}_$mode.log 2>&1
     echo "== P=$1 n=$2 bw=$3 $mode: $(tail -1 $OUT/${1}_$mode.log)"
     python3 - <<PY
