@@ -158,14 +158,16 @@ int parrm_nm_minimise_fit(parrm_nm *nm, const double *d_y, int64_t ldy, const in
 /* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host uses buffers that are
  * already page-locked in place (the fast path) -- the WHOLE range must lie inside one registration -- and
  * stages every other buffer through page-locked buffers of the call's own: it never locks caller memory
- * itself (PARRM_HOST_LOCK=1 restores that for buffers >= 64 MiB that are allocations of their own; a lock
- * covers whole pages, HIP does not count references, and a range locked, unlocked and locked again has
- * faulted under DMA on ROCm 7.2 -- profiles/r03_host_register_fault.txt).  A caller that
- * filters the same recording repeatedly -- the reference's parameter explorer re-filters on every widget
- * event (_utils/_plotting.py:568-584) -- locks it once with parrm_host_pin; the buffer must then stay
- * allocated until parrm_host_unpin, and nothing else may lock or unlock a range that shares a page with
- * it meanwhile.  Buffers that already are pinned (e.g. by the caller's allocator) are detected and left
- * alone by both entry points. */
+ * itself.  On ROCm 7.2 a host range that has been through hipHostRegister + hipHostUnregister is not safe to
+ * lock again, by this library or by the runtime (which locks pageable memory in place for large copies):
+ * the next DMA through those pages has died with a GPU memory fault at the host address
+ * (profiles/r03_host_register_fault.txt, profiles/r03_heap_fault_full_suite.txt).  Hence both entry points
+ * are NO-OPS unless the environment sets PARRM_HOST_LOCK=1 (which also lets parrm_filter_host lock buffers
+ * of >= 64 MiB that are allocations of their own): a caller that filters the same recording repeatedly --
+ * the reference's parameter explorer re-filters on every widget event (_utils/_plotting.py:568-584) --
+ * allocates page-locked memory once (hipHostMalloc, a torch pinned tensor), which both entry points
+ * detect and leave alone.  With the opt-in: the buffer must stay allocated until parrm_host_unpin, and
+ * nothing else may lock or unlock a range that shares a page with it meanwhile. */
 int parrm_host_pin(void *h_ptr, size_t bytes);
 int parrm_host_unpin(void *h_ptr);
 

@@ -137,9 +137,18 @@ static void trace_lock(const char *what, const void *p, size_t bytes, int rc) {
     if (on) fprintf(stderr, "parrm host: %s [%p, %p) %zu bytes -> %d\n", what, p, static_cast<const char *>(p) + bytes, bytes, rc);
 }
 
+// Since the end of round 3 a no-op unless PARRM_HOST_LOCK=1: on this ROCm build a host range that has been through
+// hipHostRegister + hipHostUnregister is not safe to lock again -- by anyone.  The runtime itself locks pageable
+// memory in place for large hipMemcpy transfers, so after a test had pinned and unpinned two 1-2 MB heap arrays, the
+// NEXT test's `torch.from_numpy(x).cuda()` (its array in the same, recycled heap pages) died with "Memory access
+// fault by GPU ... on address <heap address>" (profiles/r03_heap_fault_full_suite.txt; three full test runs of the
+// round ended that way, at whatever copy came next; the same signature as profiles/r03_host_register_fault.txt).
+// Buffers that are not page-locked are staged by parrm_filter_host; callers who want the in-place rate allocate
+// page-locked memory once (hipHostMalloc, a torch pinned tensor), which is never unregistered.
 int parrm_host_pin(void *h_ptr, size_t bytes) {
     PARRM_REQUIRE(h_ptr && bytes > 0, "host_pin: NULL or empty buffer");
     if (is_pinned_range(h_ptr, bytes)) return PARRM_OK;
+    if (!getenv("PARRM_HOST_LOCK")) return PARRM_OK;
     const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);
     trace_lock("pin", h_ptr, bytes, static_cast<int>(e));
     PARRM_HIP_CHECK(e);
@@ -148,7 +157,7 @@ int parrm_host_pin(void *h_ptr, size_t bytes) {
 
 int parrm_host_unpin(void *h_ptr) {
     PARRM_REQUIRE(h_ptr, "host_unpin: NULL buffer");
-    if (!is_pinned_host(h_ptr)) return PARRM_OK;
+    if (!getenv("PARRM_HOST_LOCK") || !is_pinned_host(h_ptr)) return PARRM_OK;  // (never unregisters what it did not register)
     const hipError_t e = hipHostUnregister(h_ptr);
     trace_lock("unpin", h_ptr, 0, static_cast<int>(e));
     PARRM_HIP_CHECK(e);

@@ -221,19 +221,20 @@ def test_filter_window_and_host_streaming(period, hw):
     _assert_filter_close(streamed, whole, rtol=1e-12)
     streamed32 = plan.apply_host(x.astype(np.float32), out_dtype=np.float32, chunk_samples=20000)
     _assert_filter_close(streamed32.astype(np.float64), whole, rtol=1e-5)
-    # caller-locked buffers (parrm_host_pin): same bits, the call leaves the locks in place
-    out = np.empty_like(x)
-    _hip.pin_host(x)
-    _hip.pin_host(out)
-    _hip.pin_host(out)  # idempotent
-    try:
-        for _ in range(2):
-            got = plan.apply_host(x, chunk_samples=13001, out=out)
-            assert got is out and np.array_equal(out, streamed)
-    finally:
-        _hip.unpin_host(out)
-        _hip.unpin_host(x)
-    _hip.unpin_host(x)  # not locked any more: a no-op
+    # page-locked buffers of the caller's (hipHostMalloc through torch's pinned allocator) are used in place: same bits.
+    # parrm_host_pin / parrm_host_unpin are no-ops by default (hipHostRegister + hipHostUnregister of heap pages made
+    # the NEXT pageable copy through those pages fault on this ROCm build -- include/parrm_hip.h).
+    x_locked = torch.from_numpy(x).pin_memory().numpy()
+    out = torch.empty(x.shape, dtype=torch.float64).pin_memory().numpy()
+    _hip.pin_host(out)  # already page-locked: left alone
+    for _ in range(2):
+        got = plan.apply_host(x_locked, chunk_samples=13001, out=out)
+        assert got is out and np.array_equal(out, streamed)
+    _hip.unpin_host(out)
+    plain = np.empty_like(x)
+    _hip.pin_host(plain)  # not locked (no PARRM_HOST_LOCK): the call stages it
+    assert np.array_equal(plan.apply_host(x, chunk_samples=13001, out=plain), streamed)
+    _hip.unpin_host(plain)
     with pytest.raises(ValueError):
         plan.apply_host(x, out=np.empty((2, 5)))
 

@@ -574,15 +574,11 @@ def test_config5_streaming_channel_blocks_vs_oracle():
     for out_dtype, tol in ((np.float32, 2e-6), (np.float64, 1e-10)):
         blocks = []
         for rank in range(2):
-            mine = np.ascontiguousarray(sh.shard_recording(x, rank, 2))
-            out = np.empty(mine.shape, dtype=out_dtype)
-            _hip.pin_host(mine)
-            _hip.pin_host(out)
-            try:
-                plan.apply_host(mine, out_dtype=out_dtype, chunk_samples=90_001, out=out)
-            finally:
-                _hip.unpin_host(mine)
-                _hip.unpin_host(out)
+            # (page-locked by allocation -- torch's pinned allocator = hipHostMalloc --, not by hipHostRegister: see
+            # include/parrm_hip.h on why parrm_host_pin is a no-op by default)
+            mine = torch.from_numpy(np.ascontiguousarray(sh.shard_recording(x, rank, 2))).pin_memory().numpy()
+            out = torch.empty(mine.shape, dtype=torch.float32 if out_dtype == np.float32 else torch.float64).pin_memory().numpy()
+            plan.apply_host(mine, out_dtype=out_dtype, chunk_samples=90_001, out=out)
             blocks.append(out)
         y = np.concatenate(blocks)
         assert y.dtype == out_dtype and np.abs(y - ref).max() <= tol * np.abs(ref).max()
@@ -679,32 +675,26 @@ def test_torch_exchange_over_rccl_one_rank_group():
 
 @pytest.mark.gpu
 def test_host_streaming_staged_and_locked_in_place_agree(monkeypatch):
-    """parrm_filter_host reaches the caller's buffers three ways (already locked / locked by the call when
-    >= 64 MiB / staged through the call's own page-locked buffers): same bits from all of them."""
+    """parrm_filter_host reaches the caller's buffers two ways (page-locked by their allocation: used in place /
+    anything else: staged through the call's own page-locked buffers): same bits from both."""
     rng = np.random.default_rng(12)
-    x = rng.standard_normal((9, 2_000_000)).astype(np.float32)  # 72 MB: locked in place by the call
-    assert x.nbytes >= 64 << 20
+    x = rng.standard_normal((9, 2_000_000)).astype(np.float32)  # 72 MB
     filt = orc.generate_filter(169.2359, 2372, 0, "both", 169.2359 / 50)
     plan = _hip.FilterPlan(filt)
-    locked = plan.apply_host(x, out_dtype=np.float32, chunk_samples=300_001)
-    monkeypatch.setenv("PARRM_HOST_NO_LOCK", "1")
+    x_locked = torch.from_numpy(x).pin_memory().numpy()
+    locked = plan.apply_host(x_locked, out_dtype=np.float32, chunk_samples=300_001)
     staged = plan.apply_host(x, out_dtype=np.float32, chunk_samples=300_001)
-    monkeypatch.delenv("PARRM_HOST_NO_LOCK")
     assert np.array_equal(locked, staged)
+    del x_locked
     small = np.ascontiguousarray(x[:2, :150_000])  # 1.2 MB: always staged
     got = plan.apply_host(small, out_dtype=np.float64, chunk_samples=40_000)
     ref = orc.filter_data_direct(small.astype(np.float64), filt)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
-    # a pre-locked small buffer is used in place and stays locked
-    out = np.empty_like(got)
-    _hip.pin_host(small)
-    _hip.pin_host(out)
-    try:
-        again = plan.apply_host(small, out_dtype=np.float64, chunk_samples=40_000, out=out)
-        assert again is out and np.array_equal(out, got)
-    finally:
-        _hip.unpin_host(out)
-        _hip.unpin_host(small)
+    # a small buffer that IS page-locked (by its allocation) is used in place
+    small_locked = torch.from_numpy(small).pin_memory().numpy()
+    out = torch.empty(got.shape, dtype=torch.float64).pin_memory().numpy()
+    again = plan.apply_host(small_locked, out_dtype=np.float64, chunk_samples=40_000, out=out)
+    assert again is out and np.array_equal(out, got)
 
 
 @pytest.mark.gpu
