@@ -1877,9 +1877,15 @@ static int fit_errors_impl(const double *d_y, int64_t ldy, const int64_t *d_idx,
     const bool wide = use_mfma && C > 64 && !(C <= 128 && g.nz == 1 && !getenv("PARRM_FIT_NO_TWO_WAVES"));
     const bool fused = special && wide && !getenv("PARRM_FIT_UNFUSED");
     if (fused) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(fit_accum_fused_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLdsBytes);
-        PARRM_HIP_CHECK(attr);
+        // (the attribute belongs to the function ON A DEVICE: once per device of a multi-device process)
+        static std::atomic<bool> lds_allowed[64];
+        int dev = 0;
+        PARRM_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !lds_allowed[dev].load(std::memory_order_acquire)) {
+            PARRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fit_accum_fused_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLdsBytes));
+            if (dev >= 0 && dev < 64) lds_allowed[dev].store(true, std::memory_order_release);
+        }
     } else if (special) {
         hipLaunchKernelGGL(fit_trig_packed_kernel, dim3((g.n_pad + 63) / 64, groups), dim3(64 * packed_trig_waves(K)), 0, s,
                            small, d_idx, n, g.n_pad, d_periods, P, bw, exact_trig, wmat, by_value);
