@@ -894,11 +894,20 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt) a[rt] = a_nx[rt];
             const double asp = s_nx;
-            // the next step's design rows (after the tile's last step: rows nobody uses)
+            // the next step's design rows (after the tile's last step: rows nobody uses), requested BEFORE this step's
+            // products, into registers of their own (left to itself hipcc reuses the registers and requests them after
+            // the products).  In the first step of an iteration they go out behind the first column's products instead:
+            // at the loop's head hipcc waits for lgkmcnt(0) before the first product, which with the look-ahead
+            // already out would be a wait for reads issued a few cycles earlier.
+            auto look_ahead = [&]() {
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt) a_nx[rt] = row[(4 * d + 4) * FS + lane_a + 16 * rt];
-            s_nx = row[(4 * d + 4) * FS + lane_s];
-            __builtin_amdgcn_sched_barrier(0);  // (requested BEFORE this step's products, into registers of their own)
+                for (int rt = 0; rt < 3; ++rt) a_nx[rt] = row[(4 * d + 4) * FS + lane_a + 16 * rt];
+                s_nx = row[(4 * d + 4) * FS + lane_s];
+            };
+            if (d != 0) {
+                look_ahead();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             y[0] = __builtin_bit_cast(double, u2_t{qy[d][0].x, qy[d][0].y});
             y[1] = __builtin_bit_cast(double, u2_t{qy[d][0].z, qy[d][0].w});
             y[2] = __builtin_bit_cast(double, u2_t{qy[d][1].x, qy[d][1].y});
@@ -909,6 +918,11 @@ __device__ __forceinline__ void fit_accum_fused_body(const double *Y, int64_t ld
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt)
                     acc[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], y[t], acc[rt][t], 0, 0, 0);
+                if (d == 0 && t == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    look_ahead();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             const double bw_ = wv == 0 ? a[0] : (wv == 1 ? a[1] : a[2]);
             gsp = __builtin_amdgcn_mfma_f64_16x16x4f64(asp, bw_, gsp, 0, 0, 0);
