@@ -179,6 +179,33 @@ class DeviceExchange(ThreadExchange):
         return parts
 
 
+class _AttachedSegment:
+    """Another rank's shared-memory segment, mapped read/write WITHOUT ``multiprocessing.shared_memory``: before
+    Python 3.13 that class registers attached segments with the resource tracker too, which then unlinks -- or warns
+    about -- segments this process never owned (and, where the ranks share one tracker, the owner's ``unlink`` and
+    an attacher's ``unregister`` of the same name leave a ``KeyError`` traceback in the tracker at teardown)."""
+
+    def __init__(self, name: str):
+        import mmap
+        import os
+
+        import _posixshmem
+
+        fd = _posixshmem.shm_open("/" + name.lstrip("/"), os.O_RDWR, mode=0o600)
+        try:
+            self.size = os.fstat(fd).st_size
+            self._mmap = mmap.mmap(fd, self.size)
+        finally:
+            os.close(fd)
+        self.buf = memoryview(self._mmap)
+
+    def close(self):
+        if self._mmap is not None:
+            self.buf.release()
+            self._mmap.close()
+            self._mmap = None
+
+
 class ShmExchange(Exchange):
     """One process per GPU, pieces staged through POSIX shared memory (``/dev/shm``): every rank owns one segment,
     writes its piece there (device -> host copy straight into the mapping), and reads the other ranks' segments
@@ -197,7 +224,7 @@ class ShmExchange(Exchange):
         self._tag = tag or f"parrm{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self._mine = None          # (SharedMemory, capacity)
         self._theirs = {}          # rank -> (SharedMemory, capacity)
-        self._pinned = []          # (address, segment) of page-locked mappings
+        self._staging = None       # page-locked staging buffer (uint8 tensor; False: none to be had)
         self._seq = 0
 
     def _barrier(self):
@@ -220,22 +247,25 @@ class ShmExchange(Exchange):
                 stale.unlink()
                 seg = shared_memory.SharedMemory(name=name, create=True, size=cap)
             self._mine = (seg, cap, name)
-            self._pin(seg)
         return self._mine
 
-    def _pin(self, seg):
-        """Page-lock a segment's mapping for the life of the mapping (its own, page-aligned mmap; registered once,
-        never re-registered): copies to and from it then run at the link's rate instead of the pageable path's."""
-        import ctypes
-
+    def _stage(self, nbytes: int, device_side: bool):
+        """A page-locked staging buffer of this exchange (torch's pinned allocator, i.e. an ALLOCATION, grow-only):
+        device <-> staging runs at the link's rate, staging <-> mapping is a host memcpy.  Round 3 page-locked the
+        mappings themselves with ``hipHostRegister``; a segment that grows is unmapped while registered and its
+        address range can come back with the next mapping and be registered again -- the lock / unlock / lock
+        pattern ``profiles/r03_host_register_fault.txt`` ties to GPU page faults on this runtime.
+        Nothing in this class registers host memory any more."""
         import torch
 
-        try:
-            addr = ctypes.addressof(ctypes.c_char.from_buffer(seg.buf))
-            if int(torch.cuda.cudart().cudaHostRegister(addr, seg.size, 0)) == 0:
-                self._pinned.append((addr, seg))
-        except Exception:  # noqa: BLE001 -- not page-locked: merely slower
-            pass
+        if not device_side:
+            return None
+        if self._staging is None or self._staging.numel() < nbytes:
+            try:
+                self._staging = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:  # no page-locked memory to be had: the pageable path is merely slower
+                self._staging = False
+        return self._staging if self._staging is not False and self._staging.numel() >= nbytes else None
 
     def all_gather(self, tensor):
         import torch
@@ -246,7 +276,13 @@ class ShmExchange(Exchange):
         self._seq += 1
         seg = self._segment(nbytes)
         host = torch.frombuffer(seg[0].buf, dtype=src.dtype, count=src.numel()).view(src.shape)
-        host.copy_(src)  # device -> shared memory (blocking)
+        stage = self._stage(nbytes, src.is_cuda)
+        if stage is not None:  # device -> page-locked staging -> shared memory
+            staged = stage[:nbytes].view(src.dtype).view(src.shape)
+            staged.copy_(src)  # (blocking: the destination is host memory)
+            host.copy_(staged)
+        else:
+            host.copy_(src)  # device (pageable path) or host -> shared memory, blocking
         # every rank tells the others which segment holds its piece of this round (names change when one grows)
         names = [None] * self.world_size
         self._dist.all_gather_object(names, seg[2], group=self._group)  # doubles as the "everybody has written" barrier
@@ -259,30 +295,20 @@ class ShmExchange(Exchange):
             if cur is None or cur[1] != name:
                 if cur is not None:
                     cur[0].close()
-                cur = (shared_memory.SharedMemory(name=name), name)
-                self._pin(cur[0])
-                try:  # (Python < 3.13 also registers ATTACHED segments with the resource tracker, which then
-                    #  unlinks -- or warns about -- segments this process never owned)
-                    from multiprocessing import resource_tracker
-
-                    resource_tracker.unregister(cur[0]._name, "shared_memory")
-                except Exception:
-                    pass
+                cur = (_AttachedSegment(name), name)
                 self._theirs[rank] = cur
             view = torch.frombuffer(cur[0].buf, dtype=src.dtype, count=src.numel()).view(src.shape)
-            parts.append(view.to(src.device) if src.is_cuda else view.clone())
+            if stage is not None:  # shared memory -> page-locked staging -> device
+                staged = stage[:nbytes].view(src.dtype).view(src.shape)
+                staged.copy_(view)
+                parts.append(staged.to(src.device))  # (blocking: the staging buffer is free for the next piece)
+            else:
+                parts.append(view.to(src.device) if src.is_cuda else view.clone())
         self._barrier()  # nobody rewrites its segment before every rank has read it
         return parts
 
     def close(self):
-        import torch
-
-        for addr, _seg in self._pinned:
-            try:
-                torch.cuda.cudart().cudaHostUnregister(addr)
-            except Exception:  # noqa: BLE001
-                pass
-        self._pinned = []
+        self._staging = None
         for seg in self._theirs.values():
             seg[0].close()
         self._theirs = {}

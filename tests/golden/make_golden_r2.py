@@ -19,6 +19,9 @@ Fixtures written (``r2_*.npz`` / ``r2_periods.json``):
 * ``float32``     float32 recordings (the reference standardises in float32, parrm.py:272-280).
 * ``fuzz``        60 small recordings over sampling/artefact frequency pairs, channel counts,
                   lengths, detunings and seeds: the reference's period of each.
+* ``psd``         the reference's ``compute_psd`` (_utils/_power.py:10-68) on three seeded inputs:
+                  ``n_points`` below, equal to and above the recording's length (truncation and
+                  zero padding), with and without ``max_freq``, float32 and float64 recordings.
 """
 
 from __future__ import annotations
@@ -181,11 +184,45 @@ def run_cfg1_flow():
     np.savez(os.path.join(HERE, "r2_per_site.npz"), **per)
 
 
+def psd_cases():
+    """Inputs of the ``psd`` fixture; a recording is ``synth_recording_exact(n_chans, n_times, period, seed)``."""
+    return [
+        # n_points < n_times: the first n_points samples only (scipy's fft(x, n) truncates)
+        dict(tag="trunc", n_chans=3, n_times=6000, fs=1000, n_points=2000, max_freq=None, dtype="float64",
+             period=7.6923, seed=71),
+        # n_points > n_times: zero padded; cut at max_freq
+        dict(tag="pad_maxfreq", n_chans=2, n_times=1500, fs=22000, n_points=4096, max_freq=5000.0, dtype="float64",
+             period=169.23, seed=72),
+        # odd n_points == n_times, a float32 recording, cut at max_freq
+        dict(tag="odd_f32", n_chans=4, n_times=3001, fs=250, n_points=3001, max_freq=100.0, dtype="float32",
+             period=1.923, seed=73),
+    ]
+
+
+def run_psd():
+    """The reference's own ``compute_psd`` (``/root/reference/src/pyparrm/_utils/_power.py:10-68``), unmodified."""
+    _import_reference()
+    from pyparrm._utils._power import compute_psd
+
+    out = {"cases": json.dumps(psd_cases())}
+    for case in psd_cases():
+        x = synth_recording_exact(case["n_chans"], case["n_times"], case["period"], case["seed"],
+                                  dtype=np.dtype(case["dtype"]))
+        freqs, psd = compute_psd(x, case["fs"], case["n_points"], case["max_freq"])
+        assert psd.dtype == np.float32
+        out[f"{case['tag']}_freqs"] = freqs
+        out[f"{case['tag']}_psd"] = psd
+        print("psd", case["tag"], freqs.shape, psd.shape, float(psd.max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "r2_psd.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--workers", type=int, default=6)
     args = ap.parse_args()
+    if args.only in (None, "psd"):
+        run_psd()
     if args.only in (None, "grid26"):
         run_grid26(args.only)
     if args.only in (None, "cfg1_flow"):

@@ -404,7 +404,7 @@ def test_period_example_data(golden):
     p = PARRM(x, 200, 150, verbose=False)
     p.find_period()
     assert isinstance(p.period, np.float64)
-    assert abs(p.period - ref) <= 1e-9 * ref, (p.period, ref)
+    assert p.period == ref, (repr(p.period), repr(ref))  # bit-identical, not 1e-9: taps are a step function of T
     # the full reference flow reproduces the MATLAB output (plot_use_parrm.py:135-141,239)
     p.create_filter(filter_half_width=2000, omit_n_samples=20, filter_direction="both",
                     period_half_width=0.01)
@@ -418,7 +418,7 @@ def test_period_ecog_seed44(golden):
     x = np.load(get_example_data_paths("ecog_lfp_data"))
     p = PARRM(x, 1000, 130, verbose=False)
     p.find_period(random_seed=44)
-    assert abs(p.period - ref) <= 1e-9 * ref, (p.period, ref)
+    assert p.period == ref, (repr(p.period), repr(ref))  # bit-identical, not 1e-9: taps are a step function of T
     assert _same_taps(p.period, ref, x.shape[1])
 
 
@@ -427,12 +427,12 @@ def test_period_synth_and_options(golden):
     p = PARRM(g["synth_4x30000"], 22000, 130, verbose=False)
     p.find_period(random_seed=3)
     ref = float(g["synth_4x30000_seed3"])
-    assert abs(p.period - ref) <= 1e-9 * ref, (p.period, ref)
+    assert p.period == ref, (repr(p.period), repr(ref))  # bit-identical, not 1e-9: taps are a step function of T
     assert _same_taps(p.period, ref, 30000)
     p2 = PARRM(g["synth_3x6000"], 1000, 130, verbose=False)
     p2.find_period(search_samples=np.arange(0, 3000.0), assumed_periods=(7.6, 7.7), random_seed=1)
     ref2 = float(g["synth_3x6000_half_two_estimates"])
-    assert abs(p2.period - ref2) <= 1e-9 * ref2, (p2.period, ref2)
+    assert p2.period == ref2, (repr(p2.period), repr(ref2))
 
 
 def test_period_nonfinite_data_raises():
