@@ -1,5 +1,6 @@
 // ABI plumbing: error strings, version, device count, and the host-buffer streaming form of
 // filter_data (BASELINE config 5: recordings larger than HBM, or simply host-resident).
+#include <atomic>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -137,6 +138,20 @@ static void trace_lock(const char *what, const void *p, size_t bytes, int rc) {
     if (on) fprintf(stderr, "parrm host: %s [%p, %p) %zu bytes -> %d\n", what, p, static_cast<const char *>(p) + bytes, bytes, rc);
 }
 
+// The opt-in that lets this library call hipHostRegister on caller memory.  Read at every call (a test or a caller may
+// set it late); the first call that finds it set says on stderr what it risks.
+static bool host_lock_opted_in() {
+    if (!getenv("PARRM_HOST_LOCK")) return false;
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true))
+        fprintf(stderr,
+                "pyparrm_amd: PARRM_HOST_LOCK=1 -- the library will hipHostRegister caller memory.  On ROCm 7.2 a host range that "
+                "was registered, unregistered and registered again took GPU page faults inside the re-registered range "
+                "(profiles/r03_host_register_fault.txt, profiles/r04_host_register_repro.txt); prefer page-locked "
+                "ALLOCATIONS (hipHostMalloc, a torch pinned tensor), which the library uses in place.\n");
+    return true;
+}
+
 // Since the end of round 3 a no-op unless PARRM_HOST_LOCK=1: on this ROCm build a host range that has been through
 // hipHostRegister + hipHostUnregister is not safe to lock again -- by anyone.  The runtime itself locks pageable
 // memory in place for large hipMemcpy transfers, so after a test had pinned and unpinned two 1-2 MB heap arrays, the
@@ -148,7 +163,7 @@ static void trace_lock(const char *what, const void *p, size_t bytes, int rc) {
 int parrm_host_pin(void *h_ptr, size_t bytes) {
     PARRM_REQUIRE(h_ptr && bytes > 0, "host_pin: NULL or empty buffer");
     if (is_pinned_range(h_ptr, bytes)) return PARRM_OK;
-    if (!getenv("PARRM_HOST_LOCK")) return PARRM_OK;
+    if (!host_lock_opted_in()) return PARRM_OK;
     const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);
     trace_lock("pin", h_ptr, bytes, static_cast<int>(e));
     PARRM_HIP_CHECK(e);
@@ -157,7 +172,7 @@ int parrm_host_pin(void *h_ptr, size_t bytes) {
 
 int parrm_host_unpin(void *h_ptr) {
     PARRM_REQUIRE(h_ptr, "host_unpin: NULL buffer");
-    if (!getenv("PARRM_HOST_LOCK") || !is_pinned_host(h_ptr)) return PARRM_OK;  // (never unregisters what it did not register)
+    if (!host_lock_opted_in() || !is_pinned_host(h_ptr)) return PARRM_OK;  // (never unregisters what it did not register)
     const hipError_t e = hipHostUnregister(h_ptr);
     trace_lock("unpin", h_ptr, 0, static_cast<int>(e));
     PARRM_HIP_CHECK(e);
@@ -223,7 +238,7 @@ int parrm_filter_host(const parrm_filter_plan *plan, const void *h_x, int x_dtyp
         // fault.  Unlocked buffers are staged through page-locked buffers the call owns; callers who need the
         // in-place rate allocate page-locked memory (hipHostMalloc, a torch pinned tensor) once.
         const bool own_mapping = (reinterpret_cast<uintptr_t>(p) & 4095u) <= 128u;
-        if (bytes >= kLockInPlaceMin && own_mapping && getenv("PARRM_HOST_LOCK")) {
+        if (bytes >= kLockInPlaceMin && own_mapping && host_lock_opted_in()) {
             const hipError_t er = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
             trace_lock("lock for the call", p, bytes, static_cast<int>(er));
             if (er == hipSuccess) {
