@@ -158,12 +158,18 @@ int parrm_nm_minimise_fit(parrm_nm *nm, const double *d_y, int64_t ldy, const in
 /* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host uses buffers that are
  * already page-locked in place (the fast path) -- the WHOLE range must lie inside one registration -- and
  * stages every other buffer through page-locked buffers of the call's own: it never locks caller memory
- * itself.  On ROCm 7.2 a host range that has been through hipHostRegister + hipHostUnregister is not safe to
- * lock again, by this library or by the runtime (which locks pageable memory in place for large copies):
- * the next DMA through those pages has died with a GPU memory fault at the host address
- * (profiles/r03_host_register_fault.txt, profiles/r03_heap_fault_full_suite.txt).  Hence both entry points
+ * itself.  Why: in round 3 a range this library had registered, unregistered after the call and registered again
+ * for the next call took a GPU memory fault INSIDE the re-registered range, and a later pageable copy through
+ * recycled heap pages died the same way (profiles/r03_host_register_fault.txt,
+ * profiles/r03_heap_fault_full_suite.txt; ROCm 7.2).  A library-free reproducer of the bare sequence --
+ * hipHostRegister -> hipMemcpyAsync -> hipHostUnregister -> hipHostRegister -> hipMemcpyAsync on one 128 MiB
+ * malloc, plus kernel access, threads and a recycled address (scripts/exp_host_register_repro.hip) -- ran CLEAN
+ * (profiles/r04_host_register_repro.txt): the bare runtime sequence is not sufficient, so the fault is NOT
+ * attributed to the runtime; it needed more of this library's round-3 sequence (two neighbouring ranges locked
+ * per call around chunked two-stream copies from two threads) and stays unexplained.  Not locking caller
+ * memory removes the sequence whichever side owns the defect.  Hence both entry points
  * are NO-OPS unless the environment sets PARRM_HOST_LOCK=1 (which also lets parrm_filter_host lock buffers
- * of >= 64 MiB that are allocations of their own): a caller that filters the same recording repeatedly --
+ * of >= 64 MiB that are allocations of their own; the first use prints a warning naming the files above): a caller that filters the same recording repeatedly --
  * the reference's parameter explorer re-filters on every widget event (_utils/_plotting.py:568-584) --
  * allocates page-locked memory once (hipHostMalloc, a torch pinned tensor), which both entry points
  * detect and leave alone.  With the opt-in: the buffer must stay allocated until parrm_host_unpin, and
