@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PARRM_HIP_ABI_VERSION 2
+#define PARRM_HIP_ABI_VERSION 3
 
 #define PARRM_OK 0
 #define PARRM_ERR_INVALID 1   /* bad argument (NULL, negative size, unsupported dtype...) */
@@ -35,6 +35,7 @@ extern "C" {
 #define PARRM_ERR_NO_DEVICE 3 /* no HIP device visible                                    */
 #define PARRM_ERR_WORKSPACE 4 /* caller-provided workspace too small                      */
 #define PARRM_ERR_EMPTY_FILTER 5 /* filter has no taps (parrm.py:822-827 raises before this) */
+#define PARRM_ERR_INTERNAL 6  /* a self-check of the library failed (e.g. the host's replay of a device-side refinement) */
 
 /* element types of a recording */
 #define PARRM_F32 0
@@ -147,13 +148,34 @@ int parrm_nm_next(parrm_nm *nm, double *points, int capacity, int *n);
 int parrm_nm_feed(parrm_nm *nm, const double *values, int n);
 /* (xopt, fopt, iterations, function calls) of run `run`: fmin(..., full_output=True)[:4]. */
 int parrm_nm_result(const parrm_nm *nm, int run, double *xopt, double *fopt, int *iterations, int *funcalls);
-/* The whole search on the device objective (parrm_fit_errors_host per batch) in one call.  Workspace:
+/* The whole search on the device objective in one call (replaces scipy.optimize.fmin's chain of dependent
+ * evaluations, parrm.py:499-517, :545-550): one parrm_fit_errors_host call per batch, decisions taken on the host
+ * between them.  With PARRM_NM_CHAIN=1 (a fresh object, shapes the matrix-core path takes) the refinement runs as a
+ * DEVICE-SIDE CHAIN instead: the kernel that closes a batch also takes the state machine's decisions and leaves the
+ * next batch in device memory; the host keeps the stream filled, then replays the recorded batches through this
+ * object and fails with PARRM_ERR_INTERNAL unless they agree bit for bit.  Same batches, same values either way
+ * (tests/test_gpu_parity_r2.py); the chain measured 0.65 ms slower per search on an MI355X and is not the default
+ * (profiles/r04_nm_chain_ab.txt).  Workspace:
  * parrm_nm_fit_workspace_bytes.  hist_x / hist_f / batch_sizes (may be NULL): every evaluation, batch by batch. */
 size_t parrm_nm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int bw);
 int parrm_nm_minimise_fit(parrm_nm *nm, const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
                           int64_t n_chans, int bw, double lambda, void *d_workspace, size_t workspace_bytes, void *stream,
                           double *hist_x, double *hist_f, int hist_capacity, int *batch_sizes, int batch_capacity,
                           int *n_batches);
+
+/* Counters since the library was loaded: out[0] refinements run as device-side chains, out[1] refinements stepped
+ * from the host, out[2] / out[3] the batches of each. */
+int parrm_nm_chain_stats(long long out[4]);
+
+/* The state machine the device runs (csrc/parrm_nm_core.h: plain data, no exceptions), compiled for the host: a
+ * TEST SURFACE with parrm_nm_next / _feed / _result's contracts (tests/test_neldermead.py holds it equal to the
+ * Python generator and to parrm_nm_* above); at most 8 starts. */
+int parrm_nmcore_create(const double *starts, int n_starts, double xatol, double fatol, int maxiter, int maxfun,
+                        int lookahead_runs, void **handle);
+int parrm_nmcore_destroy(void *handle);
+int parrm_nmcore_next(void *handle, double *points, int capacity, int *n);
+int parrm_nmcore_feed(void *handle, const double *values, int n);
+int parrm_nmcore_result(void *handle, int run, double *xopt, double *fopt, int *iterations, int *funcalls);
 
 /* Page-lock / unlock a host buffer for the streamed path below.  parrm_filter_host uses buffers that are
  * already page-locked in place (the fast path) -- the WHOLE range must lie inside one registration -- and

@@ -55,6 +55,12 @@ SYMBOLS = (
     "parrm_nm_result",
     "parrm_nm_fit_workspace_bytes",
     "parrm_nm_minimise_fit",
+    "parrm_nm_chain_stats",
+    "parrm_nmcore_create",
+    "parrm_nmcore_destroy",
+    "parrm_nmcore_next",
+    "parrm_nmcore_feed",
+    "parrm_nmcore_result",
 )
 
 
@@ -201,12 +207,24 @@ def lib() -> C.CDLL:
         L.parrm_nm_feed.argtypes = [vp, vp, i32]
         L.parrm_nm_result.restype = i32
         L.parrm_nm_result.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
+        L.parrm_nm_chain_stats.restype = i32
+        L.parrm_nm_chain_stats.argtypes = [vp]
+        L.parrm_nmcore_create.restype = i32
+        L.parrm_nmcore_create.argtypes = [vp, i32, dbl, dbl, i32, i32, i32, C.POINTER(vp)]
+        L.parrm_nmcore_destroy.restype = i32
+        L.parrm_nmcore_destroy.argtypes = [vp]
+        L.parrm_nmcore_next.restype = i32
+        L.parrm_nmcore_next.argtypes = [vp, vp, i32, C.POINTER(i32)]
+        L.parrm_nmcore_feed.restype = i32
+        L.parrm_nmcore_feed.argtypes = [vp, vp, i32]
+        L.parrm_nmcore_result.restype = i32
+        L.parrm_nmcore_result.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
         L.parrm_nm_fit_workspace_bytes.restype = C.c_size_t
         L.parrm_nm_fit_workspace_bytes.argtypes = [i64, i64, i32]
         L.parrm_nm_minimise_fit.restype = i32
         L.parrm_nm_minimise_fit.argtypes = [vp, vp, i64, vp, i64, i64, i32, dbl, vp, C.c_size_t, vp, vp, vp, i32, vp, i32,
                                             C.POINTER(i32)]
-        if L.parrm_hip_abi_version() != 2:
+        if L.parrm_hip_abi_version() != 3:
             raise HipLibraryError("libparrm_hip.so has an unexpected ABI version (rebuild it: make -C pyparrm_amd/csrc)")
         _lib = L
         # library-lifetime resources go back while the HIP runtime is certainly up: atexit hooks run at
@@ -686,40 +704,44 @@ class NativeNelderMead:
     the Python generator) and the whole search on the device objective in one C call (``minimise_fit``)."""
 
     MAX_BATCH = 64
+    _FAMILY = "parrm_nm"  # the entry points' prefix (NelderMeadCoreOnHost: the state machine the device runs)
+
+    def _fn(self, name):
+        return getattr(lib(), f"{self._FAMILY}_{name}")
 
     def __init__(self, starts, xtol=1e-4, ftol=1e-4, maxiter=None, maxfun=None, lookahead_runs=2):
         x0 = np.ascontiguousarray(np.asarray(starts, dtype=np.float64).reshape(-1))
         self._n = int(x0.shape[0])
         h = C.c_void_p()
-        check(lib().parrm_nm_create(x0.ctypes.data, self._n, float(xtol), float(ftol), -1 if maxiter is None else int(maxiter),
-                                    -1 if maxfun is None else int(maxfun), int(lookahead_runs), C.byref(h)), "parrm_nm_create")
+        check(self._fn("create")(x0.ctypes.data, self._n, float(xtol), float(ftol), -1 if maxiter is None else int(maxiter),
+                                 -1 if maxfun is None else int(maxfun), int(lookahead_runs), C.byref(h)), f"{self._FAMILY}_create")
         self._h = h
-        self._buf = np.empty(self.MAX_BATCH, dtype=np.float64)
+        self._buf = np.empty(max(self.MAX_BATCH, 9 * self._n), dtype=np.float64)  # (3 per run + 6 of look-ahead)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h and not _SHUT_DOWN and _lib is not None:  # (interpreter shutdown may have cleared the module already)
             try:
-                _lib.parrm_nm_destroy(h)
+                getattr(_lib, f"{self._FAMILY}_destroy")(h)
             except Exception:
                 pass
 
     def next_batch(self):
         """The next batch of abscissae (ascending float64 array), or None when every run has ended."""
         n = C.c_int32(0)
-        check(lib().parrm_nm_next(self._h, self._buf.ctypes.data, self.MAX_BATCH, C.byref(n)), "parrm_nm_next")
+        check(self._fn("next")(self._h, self._buf.ctypes.data, int(self._buf.shape[0]), C.byref(n)), f"{self._FAMILY}_next")
         return self._buf[: n.value].copy() if n.value else None
 
     def feed(self, values) -> None:
         v = np.ascontiguousarray(values, dtype=np.float64)
-        check(lib().parrm_nm_feed(self._h, v.ctypes.data, int(v.shape[0])), "parrm_nm_feed")
+        check(self._fn("feed")(self._h, v.ctypes.data, int(v.shape[0])), f"{self._FAMILY}_feed")
 
     def results(self):
         """``[(xopt[1], fopt, iterations, funcalls)]`` per start, as ``fmin_lockstep`` returns them."""
         out = []
         x, f, it, nf = dbl_t(), dbl_t(), C.c_int32(), C.c_int32()
         for r in range(self._n):
-            check(lib().parrm_nm_result(self._h, r, C.byref(x), C.byref(f), C.byref(it), C.byref(nf)), "parrm_nm_result")
+            check(self._fn("result")(self._h, r, C.byref(x), C.byref(f), C.byref(it), C.byref(nf)), f"{self._FAMILY}_result")
             out.append((np.array([x.value], dtype=np.float64), float(f.value), int(it.value), int(nf.value)))
         return out
 
@@ -727,6 +749,17 @@ class NativeNelderMead:
         """Run the search to its end on the harmonic-regression objective of the stage matrix ``y`` / indices ``idx``
         (device tensors); returns ``(results, log)`` with ``log`` the list of ``(points, errors)`` per batch."""
         torch = require_gpu()
+        if 9 * self._n > self.MAX_BATCH:
+            # more starts than one C call's batch buffer takes (the reference starts <= 5, parrm.py:499): the same
+            # refinement through the step interface, one device batch per step
+            log = []
+            while True:
+                points = self.next_batch()
+                if points is None:
+                    return self.results(), log
+                values = fit_errors(y, idx, points, bandwidth, lambda_, workspace)
+                self.feed(values)
+                log.append((points, np.asarray(values, dtype=np.float64)))
         n_idx, n_chans = (int(v) for v in y.shape)
         key = (n_idx, n_chans, int(bandwidth))
         nbytes = _NM_WORKSPACE_BYTES.get(key)
@@ -750,6 +783,17 @@ class NativeNelderMead:
             log.append((hx[at:at + n].copy(), hf[at:at + n].copy()))
             at += n
         return self.results(), log
+
+
+class NelderMeadCoreOnHost(NativeNelderMead):
+    """``csrc/parrm_nm_core.h`` -- the plain-data state machine the DEVICE runs between two optimiser batches
+    (``nm_chain_step_kernel``) -- compiled for the host: step interface only (a test surface; needs no GPU)."""
+
+    _FAMILY = "parrm_nmcore"
+    MAX_BATCH = 32
+
+    def minimise_fit(self, *args, **kwargs):
+        raise NotImplementedError("the host build of the device's state machine has the step interface only")
 
 
 def fit_errors(y, idx, periods: np.ndarray, bandwidth: int, lambda_: float, workspace: FitWorkspace | None = None,

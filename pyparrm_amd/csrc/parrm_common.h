@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "parrm_hip.h"
@@ -22,6 +23,18 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+}  // namespace parrm
+
+namespace parrm_nmcore {
+struct Core;
+}
+namespace parrm {
+// The Nelder-Mead refinement as a device-side chain (parrm_period.hip; state machine: parrm_nm_core.h).
+size_t nm_chain_workspace_bytes(int64_t n_idx, int64_t n_chans, int bw);
+int nm_chain_run(const parrm_nmcore::Core &init, const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
+                 int64_t n_chans, int bw, double lambda, void *d_workspace, size_t workspace_bytes, void *stream, double *hist_x,
+                 double *hist_f, int hist_capacity, int *batch_sizes, int batch_capacity, int *n_batches, int *hist_used,
+                 double *res_x, double *res_f, int *res_its, int *res_calls, bool *handled);
 }  // namespace parrm
 
 #define PARRM_HIP_CHECK(expr)                                          \

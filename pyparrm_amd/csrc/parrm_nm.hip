@@ -11,15 +11,18 @@
 // the same (ascending) order -- so that a whole search runs inside ONE C call (parrm_nm_minimise_fit); the step
 // interface (parrm_nm_next / parrm_nm_feed) is what tests/test_neldermead.py drives against the Python generator.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <unordered_map>
 #include <vector>
 
 #include "parrm_common.h"
 #include "parrm_hip.h"
+#include "parrm_nm_core.h"
 
 namespace {
 
@@ -201,6 +204,13 @@ struct parrm_nm {
     std::vector<Run> runs;
     Table table;
     int lookahead_runs = 2;
+    // what the object was built from (the device-side chain starts its own copy of the state machine from these)
+    std::vector<double> starts;
+    double xatol = 0, fatol = 0;
+    int maxiter = -1, maxfun = -1;
+    bool fresh() const { return state == kTop && table.empty() && std::all_of(runs.begin(), runs.end(), [](const Run &r) {
+                                    return r.iterations == 0 && r.fcalls == 0 && !r.done;
+                                }); }
     // kTop: form the next main batch; kWait: a batch is out, its values are awaited; kAdvance: values are in, the
     // pending runs take their steps; kDone: every run has ended
     enum { kTop, kWait, kAdvance, kDone } state = kTop;
@@ -290,16 +300,36 @@ struct parrm_nm {
     }
 };
 
+namespace {
+std::atomic<long long> g_chain_runs{0}, g_stepped_runs{0}, g_chain_batches{0}, g_stepped_batches{0};
+}
+
 extern "C" {
+
+int parrm_nm_chain_stats(long long out[4]) {
+    PARRM_REQUIRE(out, "nm_chain_stats: NULL argument");
+    out[0] = g_chain_runs.load();
+    out[1] = g_stepped_runs.load();
+    out[2] = g_chain_batches.load();
+    out[3] = g_stepped_batches.load();
+    return PARRM_OK;
+}
 
 int parrm_nm_create(const double *starts, int n_starts, double xatol, double fatol, int maxiter, int maxfun,
                     int lookahead_runs, parrm_nm **nm) {
-    PARRM_REQUIRE(starts && nm && n_starts > 0, "nm_create: NULL argument or no start");
-    auto *p = new parrm_nm();
-    p->lookahead_runs = lookahead_runs;
-    for (int i = 0; i < n_starts; ++i) p->runs.emplace_back(starts[i], xatol, fatol, maxiter, maxfun);
-    *nm = p;
-    return PARRM_OK;
+    try {
+        PARRM_REQUIRE(starts && nm && n_starts > 0, "nm_create: NULL argument or no start");
+        auto *p = new parrm_nm();
+        p->lookahead_runs = lookahead_runs;
+        p->starts.assign(starts, starts + n_starts);
+        p->xatol = xatol, p->fatol = fatol, p->maxiter = maxiter, p->maxfun = maxfun;
+        for (int i = 0; i < n_starts; ++i) p->runs.emplace_back(starts[i], xatol, fatol, maxiter, maxfun);
+        *nm = p;
+        return PARRM_OK;
+    } catch (const std::exception &e) {  // (nothing may cross the C boundary: std::bad_alloc from the table or the batch vectors)
+        parrm::set_error("parrm_nm_create: %s", e.what());
+        return PARRM_ERR_INTERNAL;
+    }
 }
 
 int parrm_nm_destroy(parrm_nm *nm) {
@@ -308,21 +338,31 @@ int parrm_nm_destroy(parrm_nm *nm) {
 }
 
 int parrm_nm_next(parrm_nm *nm, double *points, int capacity, int *n) {
-    PARRM_REQUIRE(nm && n, "nm_next: NULL argument");
-    PARRM_REQUIRE(nm->state != parrm_nm::kWait, "nm_next: the last batch has not been fed");
-    nm->produce();
-    *n = static_cast<int>(nm->batch.size());
-    PARRM_REQUIRE(*n <= capacity && (*n == 0 || points), "nm_next: %d points do not fit the buffer of %d", *n, capacity);
-    if (*n) std::memcpy(points, nm->batch.data(), nm->batch.size() * sizeof(double));
-    return PARRM_OK;
+    try {
+        PARRM_REQUIRE(nm && n, "nm_next: NULL argument");
+        PARRM_REQUIRE(nm->state != parrm_nm::kWait, "nm_next: the last batch has not been fed");
+        nm->produce();
+        *n = static_cast<int>(nm->batch.size());
+        PARRM_REQUIRE(*n <= capacity && (*n == 0 || points), "nm_next: %d points do not fit the buffer of %d", *n, capacity);
+        if (*n) std::memcpy(points, nm->batch.data(), nm->batch.size() * sizeof(double));
+        return PARRM_OK;
+    } catch (const std::exception &e) {  // (nothing may cross the C boundary: std::bad_alloc from the table or the batch vectors)
+        parrm::set_error("parrm_nm_next: %s", e.what());
+        return PARRM_ERR_INTERNAL;
+    }
 }
 
 int parrm_nm_feed(parrm_nm *nm, const double *values, int n) {
-    PARRM_REQUIRE(nm && values, "nm_feed: NULL argument");
-    PARRM_REQUIRE(nm->state == parrm_nm::kWait && n == static_cast<int>(nm->batch.size()),
-                  "nm_feed: no batch of %d points is waiting", n);
-    nm->feed(values);
-    return PARRM_OK;
+    try {
+        PARRM_REQUIRE(nm && values, "nm_feed: NULL argument");
+        PARRM_REQUIRE(nm->state == parrm_nm::kWait && n == static_cast<int>(nm->batch.size()),
+                      "nm_feed: no batch of %d points is waiting", n);
+        nm->feed(values);
+        return PARRM_OK;
+    } catch (const std::exception &e) {  // (nothing may cross the C boundary: std::bad_alloc from the table or the batch vectors)
+        parrm::set_error("parrm_nm_feed: %s", e.what());
+        return PARRM_ERR_INTERNAL;
+    }
 }
 
 int parrm_nm_result(const parrm_nm *nm, int run, double *xopt, double *fopt, int *iterations, int *funcalls) {
@@ -337,7 +377,7 @@ int parrm_nm_result(const parrm_nm *nm, int run, double *xopt, double *fopt, int
 enum { kNmMaxBatch = 64 };
 
 size_t parrm_nm_fit_workspace_bytes(int64_t n_idx, int64_t n_chans, int bw) {
-    size_t most = 0;
+    size_t most = parrm::nm_chain_workspace_bytes(n_idx, n_chans, bw);  // (0: a shape the device-side chain does not take)
     for (int n = 1; n <= kNmMaxBatch; ++n) {
         const size_t b = parrm_fit_workspace_bytes(n_idx, n_chans, n, bw);
         if (b == 0) return 0;
@@ -350,31 +390,161 @@ int parrm_nm_minimise_fit(parrm_nm *nm, const double *d_y, int64_t ldy, const in
                           int64_t n_chans, int bw, double lambda, void *d_workspace, size_t workspace_bytes, void *stream,
                           double *hist_x, double *hist_f, int hist_capacity, int *batch_sizes, int batch_capacity,
                           int *n_batches) {
-    PARRM_REQUIRE(nm && d_y && d_idx && d_workspace && n_batches, "nm_minimise_fit: NULL argument");
-    PARRM_REQUIRE(nm->state != parrm_nm::kWait, "nm_minimise_fit: a batch of this search is waiting for its values");
-    double x[kNmMaxBatch], f[kNmMaxBatch];
-    int used = 0, batches = 0;
-    while (true) {
-        nm->produce();
-        const int n = static_cast<int>(nm->batch.size());
-        if (n == 0) break;
-        PARRM_REQUIRE(n <= kNmMaxBatch, "nm_minimise_fit: a batch of %d abscissae (more than %d)", n, kNmMaxBatch);
-        std::memcpy(x, nm->batch.data(), n * sizeof(double));
-        const int rc = parrm_fit_errors_host(d_y, ldy, d_idx, n_idx, n_chans, x, n, bw, lambda, f, d_workspace, workspace_bytes,
-                                             stream);
-        if (rc != PARRM_OK) return rc;
-        nm->feed(f);
-        if (hist_x && hist_f && batch_sizes && used + n <= hist_capacity && batches < batch_capacity) {
-            std::memcpy(hist_x + used, x, n * sizeof(double));
-            std::memcpy(hist_f + used, f, n * sizeof(double));
-            batch_sizes[batches] = n;
+    try {
+        PARRM_REQUIRE(nm && d_y && d_idx && d_workspace && n_batches, "nm_minimise_fit: NULL argument");
+        PARRM_REQUIRE(nm->state != parrm_nm::kWait, "nm_minimise_fit: a batch of this search is waiting for its values");
+        // The refinement as a device-side chain: the device carries the state machine (parrm_nm_core.h) from batch to batch
+        // and the host only keeps the queue filled.  The host does NOT take the result on trust: the recorded batches are
+        // replayed through this object's own state machine (written independently: exceptions, a hash map) and the run is
+        // refused unless every batch's abscissae and every run's result agree bit for bit.
+        if (nm->fresh() && static_cast<int>(nm->runs.size()) <= parrm_nmcore::kMaxRuns) {
+            static thread_local std::vector<double> cx, cf;
+            static thread_local std::vector<int> csz;
+            cx.resize(4096), cf.resize(4096), csz.resize(1024);
+            parrm_nmcore::Core init;
+            std::memset(&init, 0, sizeof init);
+            parrm_nmcore::core_init(init, nm->starts.data(), static_cast<int>(nm->starts.size()), nm->xatol, nm->fatol, nm->maxiter,
+                                    nm->maxfun, nm->lookahead_runs);
+            double rx[parrm_nmcore::kMaxRuns], rf[parrm_nmcore::kMaxRuns];
+            int rits[parrm_nmcore::kMaxRuns], rcalls[parrm_nmcore::kMaxRuns];
+            int nb = 0, used = 0;
+            bool handled = false;
+            const int rc = parrm::nm_chain_run(init, d_y, ldy, d_idx, n_idx, n_chans, bw, lambda, d_workspace, workspace_bytes, stream,
+                                               cx.data(), cf.data(), 4096, csz.data(), 1024, &nb, &used, rx, rf, rits, rcalls, &handled);
+            if (rc != PARRM_OK) return rc;
+            if (handled) {
+                int at = 0;
+                for (int b = 0; b < nb; ++b) {
+                    nm->produce();
+                    const int n = static_cast<int>(nm->batch.size());
+                    bool same = n == csz[b] && n > 0;
+                    for (int i = 0; same && i < n; ++i) same = key_of(nm->batch[i]) == key_of(cx[at + i]);
+                    if (!same) {
+                        parrm::set_error("nm_minimise_fit: batch %d of the device-side refinement differs from the host's replay", b);
+                        return PARRM_ERR_INTERNAL;
+                    }
+                    nm->feed(cf.data() + at);
+                    at += n;
+                }
+                nm->produce();
+                bool same = nm->batch.empty() && nm->state == parrm_nm::kDone && at == used;
+                for (size_t r = 0; same && r < nm->runs.size(); ++r) {
+                    double x, f;
+                    int its, calls;
+                    nm->runs[r].result(&x, &f, &its, &calls);
+                    same = key_of(x) == key_of(rx[r]) && (key_of(f) == key_of(rf[r]) || (is_nan(f) && is_nan(rf[r]))) && its == rits[r] &&
+                           calls == rcalls[r];
+                }
+                if (!same) {
+                    parrm::set_error("nm_minimise_fit: the device-side refinement's results differ from the host's replay");
+                    return PARRM_ERR_INTERNAL;
+                }
+                if (hist_x && hist_f && batch_sizes && used <= hist_capacity && nb <= batch_capacity) {
+                    std::memcpy(hist_x, cx.data(), static_cast<size_t>(used) * sizeof(double));
+                    std::memcpy(hist_f, cf.data(), static_cast<size_t>(used) * sizeof(double));
+                    std::memcpy(batch_sizes, csz.data(), static_cast<size_t>(nb) * sizeof(int));
+                }
+                *n_batches = nb;
+                ++g_chain_runs;
+                g_chain_batches += nb;
+                PARRM_REQUIRE(!hist_x || (used <= hist_capacity && nb <= batch_capacity),
+                              "nm_minimise_fit: the history (%d evaluations in %d batches) does not fit the buffers", used, nb);
+                return PARRM_OK;
+            }
         }
-        used += n;
-        ++batches;
+        double x[kNmMaxBatch], f[kNmMaxBatch];
+        int used = 0, batches = 0;
+        while (true) {
+            nm->produce();
+            const int n = static_cast<int>(nm->batch.size());
+            if (n == 0) break;
+            PARRM_REQUIRE(n <= kNmMaxBatch, "nm_minimise_fit: a batch of %d abscissae (more than %d)", n, kNmMaxBatch);
+            std::memcpy(x, nm->batch.data(), n * sizeof(double));
+            const int rc = parrm_fit_errors_host(d_y, ldy, d_idx, n_idx, n_chans, x, n, bw, lambda, f, d_workspace, workspace_bytes,
+                                                 stream);
+            if (rc != PARRM_OK) return rc;
+            nm->feed(f);
+            if (hist_x && hist_f && batch_sizes && used + n <= hist_capacity && batches < batch_capacity) {
+                std::memcpy(hist_x + used, x, n * sizeof(double));
+                std::memcpy(hist_f + used, f, n * sizeof(double));
+                batch_sizes[batches] = n;
+            }
+            used += n;
+            ++batches;
+        }
+        *n_batches = batches;
+        ++g_stepped_runs;
+        g_stepped_batches += batches;
+        PARRM_REQUIRE(!hist_x || (used <= hist_capacity && batches <= batch_capacity),
+                      "nm_minimise_fit: the history (%d evaluations in %d batches) does not fit the buffers", used, batches);
+        return PARRM_OK;
+    } catch (const std::exception &e) {  // (nothing may cross the C boundary: std::bad_alloc from the table or the batch vectors)
+        parrm::set_error("parrm_nm_minimise_fit: %s", e.what());
+        return PARRM_ERR_INTERNAL;
     }
-    *n_batches = batches;
-    PARRM_REQUIRE(!hist_x || (used <= hist_capacity && batches <= batch_capacity),
-                  "nm_minimise_fit: the history (%d evaluations in %d batches) does not fit the buffers", used, batches);
+}
+
+// ---- the plain-data state machine the DEVICE runs (parrm_nm_core.h), compiled for the host: test surface ------------
+// tests/test_neldermead.py drives these against the Python generator exactly as it drives parrm_nm_* above; no GPU.
+struct parrm_nmcore_handle {
+    parrm_nmcore::Core core;
+    std::vector<uint64_t> keys;
+    std::vector<double> vals;
+    int n = 0;
+    parrm_nmcore::FlatTable table() { return parrm_nmcore::FlatTable{keys.data(), vals.data(), &n, static_cast<int>(keys.size())}; }
+};
+
+int parrm_nmcore_create(const double *starts, int n_starts, double xatol, double fatol, int maxiter, int maxfun,
+                        int lookahead_runs, void **handle) {
+    try {
+        PARRM_REQUIRE(starts && handle && n_starts > 0 && n_starts <= parrm_nmcore::kMaxRuns, "nmcore_create: 1..%d starts",
+                      parrm_nmcore::kMaxRuns);
+        auto *h = new parrm_nmcore_handle();
+        std::memset(&h->core, 0, sizeof h->core);
+        parrm_nmcore::core_init(h->core, starts, n_starts, xatol, fatol, maxiter, maxfun, lookahead_runs);
+        h->keys.resize(1 << 16);
+        h->vals.resize(1 << 16);
+        *handle = h;
+        return PARRM_OK;
+    } catch (const std::exception &e) {  // (nothing may cross the C boundary: std::bad_alloc from the table or the batch vectors)
+        parrm::set_error("parrm_nmcore_create: %s", e.what());
+        return PARRM_ERR_INTERNAL;
+    }
+}
+
+int parrm_nmcore_destroy(void *handle) {
+    delete static_cast<parrm_nmcore_handle *>(handle);
+    return PARRM_OK;
+}
+
+int parrm_nmcore_next(void *handle, double *points, int capacity, int *n) {
+    auto *h = static_cast<parrm_nmcore_handle *>(handle);
+    PARRM_REQUIRE(h && n, "nmcore_next: NULL argument");
+    PARRM_REQUIRE(h->core.state != parrm_nmcore::kWait, "nmcore_next: the last batch has not been fed");
+    auto t = h->table();
+    parrm_nmcore::core_produce(h->core, t);
+    PARRM_REQUIRE(h->core.error == 0, "nmcore_next: the state machine gave up (code %d)", h->core.error);
+    *n = h->core.n_batch;
+    PARRM_REQUIRE(*n <= capacity && (*n == 0 || points), "nmcore_next: %d points do not fit the buffer of %d", *n, capacity);
+    if (*n) std::memcpy(points, h->core.batch, static_cast<size_t>(*n) * sizeof(double));
+    return PARRM_OK;
+}
+
+int parrm_nmcore_feed(void *handle, const double *values, int n) {
+    auto *h = static_cast<parrm_nmcore_handle *>(handle);
+    PARRM_REQUIRE(h && values, "nmcore_feed: NULL argument");
+    PARRM_REQUIRE(h->core.state == parrm_nmcore::kWait && n == h->core.n_batch, "nmcore_feed: no batch of %d points is waiting", n);
+    auto t = h->table();
+    parrm_nmcore::core_feed(h->core, t, values);
+    PARRM_REQUIRE(h->core.error == 0, "nmcore_feed: the table is full");
+    return PARRM_OK;
+}
+
+int parrm_nmcore_result(void *handle, int run, double *xopt, double *fopt, int *iterations, int *funcalls) {
+    auto *h = static_cast<parrm_nmcore_handle *>(handle);
+    PARRM_REQUIRE(h && xopt && fopt && iterations && funcalls, "nmcore_result: NULL argument");
+    PARRM_REQUIRE(run >= 0 && run < h->core.n_runs, "nmcore_result: no run %d", run);
+    parrm_nmcore::run_result(h->core.runs[run], xopt, fopt, iterations, funcalls);
     return PARRM_OK;
 }
 

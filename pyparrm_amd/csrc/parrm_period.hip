@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "parrm_common.h"
+#include "parrm_nm_core.h"
 
 namespace {
 
@@ -1643,6 +1644,437 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw, 
     return g;
 }
 
+// ---- the Nelder-Mead refinement as a device-side chain (round 4) ---------------------------------------------------
+// The reference's fmin runs (parrm.py:499-517, :545-550) are ~76 dependent batches per search.  Until round 3 every
+// batch went Gram -> reduce -> solve -> finish -> host (spin on a flag, take SciPy's decisions, launch the next
+// batch): ~15 us of idle device per batch.  Here the refinement's state -- the runs' simplices, the table of known
+// values, the batch that is out -- lives in device memory: the kernel that closes a batch (nm_chain_step_kernel, one
+// wave) forms the errors, feeds them to parrm_nm_core.h's state machine and leaves the NEXT batch's abscissae and
+// launch geometry in NmChainState, where the next batch's kernels read them.  Those kernels are launched with the
+// largest grid any batch size needs and blocks beyond the current batch's geometry return at once, so the host
+// enqueues batches AHEAD of the device (parrm::nm_chain_run) and only watches a progress word; once the state says
+// "finished" every kernel still queued returns at its first instruction.  A batch of P candidates is planned exactly
+// as parrm_fit_errors_host plans it (fit_geometry per P, tabulated), runs the same kernel bodies and adds in the same
+// order: the errors -- hence SciPy's decisions -- are the host-stepped path's bits, which the host checks by replaying
+// the recorded batches through parrm_nm.hip's independent state machine.
+constexpr int kChainTable = 1024;      // known values per refinement (typical ~250-400; more: the host-stepped path)
+constexpr int kChainHist = 4096;       // evaluations recorded for the host's replay
+constexpr int kChainBatches = 1024;    // batches recorded
+enum { kChainRunning = 0, kChainFinished = 1, kChainError = 2 };
+
+struct NmChainState {
+    parrm_nmcore::Core core;
+    int status;              // kChainRunning / kChainFinished / kChainError + code
+    int n_periods;           // the batch that is out: candidates, sample slices, 48-row stacks
+    int nsplit, groups;
+    int batches, hist_used;  // completed so far
+    int n_table, arrivals;
+    int nsplit_of[parrm_nmcore::kMaxBatch + 1], groups_of[parrm_nmcore::kMaxBatch + 1];  // fit_geometry per batch size
+};
+
+struct NmChainHost {  // page-locked, device-mapped: what the host watches and replays
+    volatile unsigned long long progress;  // sequence number of the last step kernel that ran
+    volatile long long status;             // (run id << 8) | kChain* once the refinement has ended
+    double res_x[parrm_nmcore::kMaxRuns], res_f[parrm_nmcore::kMaxRuns];
+    int res_its[parrm_nmcore::kMaxRuns], res_calls[parrm_nmcore::kMaxRuns];
+    int n_batches, hist_used, error, pad_;
+    int batch_sizes[kChainBatches];
+    double hist_x[kChainHist], hist_f[kChainHist];
+    NmChainState init;                     // staging of the initial state (copied to the device by the stream)
+};
+
+// The table of known values as the step kernel sees it: an open-addressing hash table in LDS (2 048 slots for at most
+// kChainTable = 1 024 entries), rebuilt at every launch from the append-only arrays in device memory.  A lookup is a
+// per-lane operation (1-2 probes), so lane r can run run r's SciPy step (parrm_nmcore::run_advance, the host's code)
+// while its neighbours run theirs.
+constexpr int kChainSlots = 2048;
+constexpr unsigned long long kChainEmpty = ~0ull;  // (a NaN pattern: NaN abscissae are never stored)
+struct LdsHash {
+    unsigned long long *keys;
+    double *vals;
+    __device__ static int home(unsigned long long k) {
+        k ^= k >> 29;
+        k *= 0x9E3779B97F4A7C15ull;
+        return static_cast<int>(k >> (64 - 11));
+    }
+    __device__ int slot_of(double x) const {
+        const unsigned long long k = parrm_nmcore::key_of(x);
+        int h = home(k);
+        for (int probes = 0; probes < kChainSlots; ++probes) {
+            const unsigned long long cur = keys[h];
+            if (cur == k) return h;
+            if (cur == kChainEmpty) return -1;
+            h = (h + 1) & (kChainSlots - 1);
+        }
+        return -1;
+    }
+    __device__ bool known(double x) const { return slot_of(x) >= 0; }
+    __device__ bool find(double x, double *val) const {
+        const int h = slot_of(x);
+        if (h < 0) return false;
+        *val = vals[h];
+        return true;
+    }
+    // (lanes insert different keys at the same time) returns false when the key was there already
+    __device__ bool insert_new(double x, double val) {
+        const unsigned long long k = parrm_nmcore::key_of(x);
+        int h = home(k);
+        for (int probes = 0; probes < kChainSlots; ++probes) {
+            const unsigned long long old = atomicCAS(&keys[h], kChainEmpty, k);
+            if (old == kChainEmpty) {
+                vals[h] = val;
+                return true;
+            }
+            if (old == k) {
+                vals[h] = val;
+                return false;
+            }
+            h = (h + 1) & (kChainSlots - 1);
+        }
+        return false;
+    }
+};
+
+// ascending, one entry per key, of the values the lanes in `valid` hold (parrm_nmcore::sort_unique for a wave):
+// out[rank] = value; returns the count.  tmp: 64 doubles of LDS.
+__device__ inline int wave_sort_unique(double v, bool valid, double *tmp, double *out) {
+    const int lane = threadIdx.x & 63;
+    tmp[lane] = v;
+    __syncthreads();
+    unsigned long long mask = __ballot(valid);
+    const unsigned long long kv = parrm_nmcore::key_of(v);
+    bool dup = false;
+    int rank = 0;
+    for (unsigned long long m = mask; m; m &= m - 1) {
+        const int j = __ffsll(static_cast<long long>(m)) - 1;
+        const double o = tmp[j];
+        if (j < lane && parrm_nmcore::key_of(o) == kv) dup = true;
+    }
+    const bool keep = valid && !dup;
+    const unsigned long long kept = __ballot(keep);
+    for (unsigned long long m = kept; m; m &= m - 1) {
+        const int j = __ffsll(static_cast<long long>(m)) - 1;
+        if (tmp[j] < v) ++rank;
+    }
+    __syncthreads();
+    if (keep) out[rank] = v;
+    __syncthreads();
+    return __popcll(kept);
+}
+
+// Closes a batch and opens the next (one wave).  `first`: nothing is out yet -- the launch that takes the initial state
+// from the host's block and forms batch 0.
+// Errors of the batch that is out: K = 41 (`quarters`): the one-wave solves left quarter sums in row KP of the
+// candidates' blocks -- added as fit_finish_kernel adds them; else fit_solve_fast_kernel<K, 4> left err[p].
+// The state machine is parrm_nm_core.h's: run_advance / run_wanted / run_lookahead per lane (lane r = run r), the
+// generator's bookkeeping (core_produce) restated over ballots.
+struct ChainStepLds {
+    parrm_nmcore::Core c;
+    unsigned long long keys[kChainSlots];
+    double vals[kChainSlots];
+    double tmp[64], list[64], need[64];
+    int fail;
+};
+__device__ inline void nm_chain_step(ChainStepLds &L, NmChainState *st, unsigned long long *keys_g, double *vals_g,
+                                     const double *part, const double *red, const double *err, int KP, int nz, int n_chans,
+                                     int quarters, NmChainHost *host, unsigned long long seq, long long run_id, int first,
+                                     int p_cap) {
+    using namespace parrm_nmcore;
+    const int lane = threadIdx.x & 63;
+    Core &c = L.c;
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(first ? &host->init.core : &st->core);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&c);
+        for (int i = lane; i < static_cast<int>(sizeof(Core) / 8); i += 64) dst[i] = src[i];
+        for (int i = lane; i < kChainSlots; i += 64) L.keys[i] = kChainEmpty;
+        if (lane == 0) L.fail = 0;
+    }
+    __syncthreads();
+    LdsHash table{L.keys, L.vals};
+    int n_table = first ? 0 : st->n_table;
+    int batches = first ? 0 : st->batches, used = first ? 0 : st->hist_used;
+    const int nsplit_out = first ? 1 : st->nsplit;
+    // the errors of the batch that is out are requested before its size is known (lanes beyond it read cells nobody
+    // uses: the blocks of p_cap candidates are inside the workspace), so that their latency overlaps the table's
+    double e_mine = 0.0;
+    if (!first && lane < p_cap) {
+        if (quarters) {
+            const double *blocks = nsplit_out > 1 ? red : part;
+            const int64_t elems = static_cast<int64_t>(KP + 1) * kNCol;
+            double total = 0.0;
+            for (int zb = 0; zb < nz; ++zb) {
+                const double *q = blocks + (static_cast<int64_t>(lane) * nz + zb) * elems + KP * kNCol + kYCols;
+                total += (q[0] + q[1]) + (q[2] + q[3]);
+            }
+            e_mine = total / static_cast<double>(n_chans);  // :597
+        } else {
+            e_mine = err[lane];
+        }
+    }
+    for (int i = lane; i < n_table; i += 64) table.insert_new(__longlong_as_double(static_cast<long long>(keys_g[i])), vals_g[i]);
+    __syncthreads();
+    if (!first) {
+        const int P = c.n_batch;
+        if (batches >= kChainBatches || used + P > kChainHist || n_table + P > kChainTable || P > p_cap) {
+            if (lane == 0) L.fail = 3;  // history or table full: the host takes the stepped path
+        } else if (lane < P) {
+            const double e = e_mine;
+            const double x = c.batch[lane];
+            host->hist_x[used + lane] = x;
+            host->hist_f[used + lane] = e;
+            if (lane == 0) host->batch_sizes[batches] = P;
+            if (!table.insert_new(x, e)) L.fail = 4;  // (a batch never holds a known abscissa)
+            keys_g[n_table + lane] = key_of(x);
+            vals_g[n_table + lane] = e;
+        }
+        __syncthreads();
+        if (!L.fail) {
+            n_table += P;
+            used += P;
+            ++batches;
+            if (lane == 0) c.state = kAdvance;
+        }
+        __syncthreads();
+    }
+    // the generator (parrm_nmcore::core_produce) up to its next batch or its end
+    int n_batch = 0;
+    while (!L.fail) {
+        if (c.state == kDone) break;
+        if (c.state == kTop) {
+            const bool is_active = lane < c.n_runs && !c.runs[lane].done;
+            const unsigned long long active = __ballot(is_active);
+            if (active == 0) {
+                __syncthreads();
+                if (lane == 0) c.state = kDone;
+                __syncthreads();
+                break;
+            }
+            double w[3] = {0, 0, 0};
+            int nw = 0;
+            if (is_active) nw = run_wanted(c.runs[lane], w);
+            __syncthreads();
+            // the runs' abscissae, ascending, one of each; then those not known yet (order kept)
+            int n_want = 0;
+            {
+                // three rounds (k-th abscissa of every run), merged through the list: values sit in lanes 0 .. 23
+                if (lane < 24) L.need[lane] = 0.0;
+                __syncthreads();
+                if (is_active)
+                    for (int k = 0; k < nw; ++k) L.need[3 * lane + k] = w[k];
+                __syncthreads();
+                bool valid = false;
+                double v = 0.0;
+                if (lane < 3 * kMaxRuns) {
+                    const int r = lane / 3, k = lane - 3 * r;
+                    const bool act = (active >> r) & 1ull;
+                    const int cnt = act ? (c.runs[r].iterations == 0 ? 2 : 3) : 0;
+                    v = L.need[lane];
+                    valid = k < cnt && !is_nan(v);
+                }
+                __syncthreads();
+                n_want = wave_sort_unique(v, valid, L.tmp, L.list);
+            }
+            const bool asks = lane < n_want;
+            const double xq = asks ? L.list[lane] : 0.0;
+            const bool unknown = asks && !table.known(xq);
+            const unsigned long long unk = __ballot(unknown);
+            int n_need = __popcll(unk);
+            __syncthreads();
+            if (unknown) L.need[__popcll(unk & ((1ull << lane) - 1ull))] = xq;
+            if (lane == 0) {
+                c.pending = static_cast<unsigned>(active);
+                c.state = kAdvance;
+            }
+            __syncthreads();
+            if (n_need > 0) {
+                if (__popcll(active) <= c.lookahead_runs) {
+                    // the likely following step's abscissae of every run in flight: lane 8 r + k holds the k-th of run r
+                    const int r = lane >> 3, k = lane & 7;
+                    bool valid = false;
+                    double v = 0.0;
+                    if (r < c.n_runs && ((active >> r) & 1ull) && k < 6) {
+                        double a[6];
+                        const int n = run_lookahead(c.runs[r], a);
+                        if (k < n) {
+                            v = a[k];
+                            valid = !is_nan(v) && !table.known(v);
+                        }
+                    }
+                    // appended behind the wanted ones, then everything sorted again (as the host does)
+                    const unsigned long long extra = __ballot(valid);
+                    __syncthreads();
+                    if (valid) L.list[n_need + __popcll(extra & ((1ull << lane) - 1ull))] = v;
+                    if (lane < n_need) L.list[lane] = L.need[lane];
+                    __syncthreads();
+                    const int total = n_need + __popcll(extra);
+                    const bool has = lane < total;
+                    const double vv = has ? L.list[lane] : 0.0;
+                    __syncthreads();
+                    n_need = wave_sort_unique(vv, has, L.tmp, L.need);
+                }
+                if (n_need > p_cap) {  // (the batch kernels' grids are cut for p_cap candidates)
+                    if (lane == 0) L.fail = 4 + kErrBatchTooLarge;
+                    __syncthreads();
+                    break;
+                }
+                if (lane < n_need) c.batch[lane] = L.need[lane];
+                if (lane == 0) {
+                    c.n_batch = n_need;
+                    c.state = kWait;
+                }
+                n_batch = n_need;
+                __syncthreads();
+                break;
+            }
+        }
+        // kAdvance: the steps of the pending runs, lane r = run r
+        const bool due = lane < c.n_runs && ((c.pending >> lane) & 1u);
+        double m = 0.0;
+        bool missed = false;
+        if (due) missed = run_advance(c.runs[lane], table, &m) != 0;
+        const unsigned long long still = __ballot(missed);
+        __syncthreads();
+        if (still == 0) {
+            if (lane == 0) c.state = kTop;
+            __syncthreads();
+            continue;
+        }
+        // expansion / shrink points of the few runs that need them
+        const int n_missing = wave_sort_unique(m, missed, L.tmp, L.need);
+        if (lane < n_missing) c.batch[lane] = L.need[lane];
+        if (lane == 0) {
+            c.n_batch = n_missing;
+            c.pending = static_cast<unsigned>(still);
+            c.state = kWait;
+        }
+        n_batch = n_missing;
+        __syncthreads();
+        break;
+    }
+    __syncthreads();
+    const int fail = L.fail;
+    const bool ended = fail || c.state == kDone;
+    if (ended && lane == 0) c.n_batch = 0;
+    __syncthreads();
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&c);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&st->core);
+        for (int i = lane; i < static_cast<int>(sizeof(Core) / 8); i += 64) dst[i] = src[i];
+    }
+    if (lane == 0) {
+        const int P = ended ? 0 : n_batch;
+        const int *nsplit_of = first ? host->init.nsplit_of : st->nsplit_of;
+        const int *groups_of = first ? host->init.groups_of : st->groups_of;
+        st->n_periods = P;
+        st->nsplit = nsplit_of[P];
+        st->groups = groups_of[P];
+        st->n_table = n_table;
+        st->batches = batches;
+        st->hist_used = used;
+        st->arrivals = 0;
+        st->status = ended ? (fail ? kChainError + fail : kChainFinished) : kChainRunning;
+    }
+    if (first)
+        for (int i = lane; i <= kMaxBatch; i += 64) {
+            st->nsplit_of[i] = host->init.nsplit_of[i];
+            st->groups_of[i] = host->init.groups_of[i];
+        }
+    if (ended) {
+        if (lane < c.n_runs) {
+            double x, f;
+            int its, calls;
+            run_result(c.runs[lane], &x, &f, &its, &calls);
+            host->res_x[lane] = x;
+            host->res_f[lane] = f;
+            host->res_its[lane] = its;
+            host->res_calls[lane] = calls;
+        }
+        if (lane == 0) {
+            host->n_batches = batches;
+            host->hist_used = used;
+            host->error = fail;
+        }
+    }
+    // The host reads the history and the results only once the status word says the refinement has ended: that is the
+    // one place where the order of the stores to its block matters.  In between, `progress` only paces its queue.
+    if (ended) {
+        __threadfence_system();
+        __syncthreads();
+        if (lane == 0) {
+            host->status = (run_id << 8) | (fail ? kChainError : kChainFinished);
+            __threadfence_system();
+        }
+    }
+    if (lane == 0) host->progress = seq;
+}
+__global__ void __launch_bounds__(64) nm_chain_step_kernel(NmChainState *st, unsigned long long *keys_g, double *vals_g,
+                                                            const double *part, const double *red, const double *err, int KP,
+                                                            int nz, int n_chans, int quarters, NmChainHost *host,
+                                                            unsigned long long seq, long long run_id, int first, int p_cap) {
+    if (!first && st->status != kChainRunning) return;
+    __shared__ ChainStepLds L;
+    nm_chain_step(L, st, keys_g, vals_g, part, red, err, KP, nz, n_chans, quarters, host, seq, run_id, first, p_cap);
+}
+
+// The batch's kernels: the bodies of the plain kernels on the geometry the state names.
+// The batch's abscissae are read through the CONSTANT address space, as the plain kernels read theirs from the kernarg
+// segment: the state does not change while a batch kernel runs, and as an ordinary global pointer the compiler must
+// assume the kernel's own stores alias it -- it then fetches the periods with vector loads, which sit in the Gram
+// kernel's hand-counted vmcnt queue (measured: +20 us per Gram launch of an optimiser batch).
+typedef const double __attribute__((address_space(4))) * ConstDoublePtr;
+__device__ __forceinline__ const double *chain_periods(const NmChainState *st) {
+    return (const double *)(ConstDoublePtr)(st->core.batch);  // (C casts: they cross address spaces)
+}
+// A Gram launch numbers its (sample slice, stack) blocks in ONE dimension and cuts that number by the batch's own slice
+// count: the blocks that have work are then the FIRST nsplit x groups of the launch, in the order a launch cut for the
+// batch would dispatch them, and the surplus comes last.  (With a two-dimensional grid of the widest geometry the
+// surplus blocks of every row sat between the working ones: they return at once, but the slots they free are refilled
+// out of step, some CUs end up with three or four working blocks and others with one -- measured +45 ... +130 us on
+// the batches whose slice count is below the widest, 56 / 51 / 46 / 39 against 64.)
+__device__ __forceinline__ Blk chain_gram_block(int nsplit) {
+    const int id = static_cast<int>(blockIdx.x);
+    const int y = id / nsplit;
+    return Blk{id - y * nsplit, y, static_cast<int>(blockIdx.z), static_cast<int>(gridDim.z)};
+}
+__global__ void __launch_bounds__(384) nm_chain_trig_kernel(const NmChainState *st, const int64_t *idx, int n_idx, int n_pad,
+                                                             int bw, double *Ws) {
+    if (st->status != kChainRunning || static_cast<int>(blockIdx.y) >= st->groups) return;
+    fit_trig_packed_body(idx, n_idx, n_pad, chain_periods(st), st->n_periods, bw, 0, Ws, this_block());
+}
+__global__ void __launch_bounds__(256) nm_chain_fused_kernel(const NmChainState *st, const double *Y, int64_t ldy,
+                                                              const int64_t *idx, int n_pad, int n_idx, int n_chans, int kpc,
+                                                              double *part, int kreal) {
+    if (st->status != kChainRunning) return;
+    const int nsplit = st->nsplit;
+    const Blk blk = chain_gram_block(nsplit);
+    if (blk.y >= st->groups) return;
+    fit_accum_fused_body(Y, ldy, idx, chain_periods(st), n_pad, n_idx, n_chans, st->n_periods, kpc, nsplit, part, blk, kreal);
+}
+template <int NW, int CT>
+__global__ void __launch_bounds__(256) nm_chain_accum_kernel(const NmChainState *st, const double *Y, int64_t ldy,
+                                                              const double *Ws, int n_pad, int n_idx, int n_chans, int kpc,
+                                                              double *part, int kreal) {
+    if (st->status != kChainRunning) return;
+    const int nsplit = st->nsplit;
+    const Blk blk = chain_gram_block(nsplit);
+    if (blk.y >= st->groups) return;
+    fit_accum_mfma_body<NW, CT, 2>(Y, ldy, Ws, n_pad, n_idx, n_chans, st->n_periods, kpc, nsplit, part, blk, kreal);
+}
+__global__ void __launch_bounds__(256) nm_chain_reduce_kernel(const NmChainState *st, const double *part, int64_t elems, int nz,
+                                                               int n_chans, double *red, int ksp) {
+    if (st->status != kChainRunning) return;
+    const int nsplit = st->nsplit;
+    if (nsplit <= 1 || static_cast<int>(blockIdx.y) >= st->n_periods * nz) return;
+    fit_reduce_body(part, nsplit, elems, nz, n_chans, red, this_block(), ksp);
+}
+template <int K, int NW>
+__global__ void __launch_bounds__(64 * NW) nm_chain_solve_kernel(const NmChainState *st, const double *part, const double *red,
+                                                                   int n_idx, int n_chans, int KP, int nz, double lambda,
+                                                                   double *err) {
+    if (st->status != kChainRunning || static_cast<int>(blockIdx.x) >= st->n_periods) return;
+    fit_solve_fast_body<K, NW>(st->nsplit > 1 ? red : part, n_idx, n_chans, KP, nz, lambda, err, this_block(), 1);
+}
+
 // ---- host hand-off of the small optimiser batches ---------------------------------------------
 // One Nelder-Mead step is a handful of candidates; the D2H copy + stream synchronise of the plain
 // path cost more host time (~40 us) than some of the kernels.  Instead a one-wave kernel at the end
@@ -1669,6 +2101,9 @@ struct HostStage {
     // gang launches: problem table | quarter flags | periods, page-locked on the host and its device copy
     static constexpr size_t kGangBytes = kMaxProblems * (sizeof(GangProblem) + sizeof(int)) + kCap * sizeof(double);
     unsigned char *h_gang = nullptr, *d_gang = nullptr;
+    // device-side Nelder-Mead chain: progress word, results and the history the host replays (mapped, see NmChainHost)
+    NmChainHost *h_chain = nullptr, *d_chain = nullptr;
+    long long chain_runs = 0;
     int device = -1;
     unsigned long long seq = 0;
     hipStream_t side[kStreams] = {};
@@ -1687,7 +2122,22 @@ struct HostStage {
         if (h_gang) (void)hipHostFree(h_gang);
         if (d_gang) (void)hipFree(d_gang);
         h_gang = d_gang = nullptr;
+        if (h_chain) (void)hipHostFree(h_chain);
+        h_chain = d_chain = nullptr;
         device = -1;
+    }
+    bool chain_ready() {
+        if (h_chain) return true;
+        void *p = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&p, sizeof(NmChainHost), hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
+            (void)hipHostFree(p);
+            return false;
+        }
+        std::memset(p, 0, sizeof(NmChainHost));
+        h_chain = static_cast<NmChainHost *>(p);
+        d_chain = static_cast<NmChainHost *>(dp);
+        return true;
     }
     bool gang_ready() {
         if (h_gang && d_gang) return true;
@@ -2306,3 +2756,246 @@ int parrm_hip_shutdown(void) {
 }
 
 }  // extern "C"
+
+// ---- host side of the device-carried Nelder-Mead chain (see NmChainState) ------------------------------------------
+namespace parrm {
+
+namespace {
+struct ChainPlan {
+    FitGeom widest;          // n_pad, KP, nz (the same for every batch size)
+    size_t w_bytes = 0, part_bytes = 0, red_bytes = 0;
+    int max_nsplit = 1, max_groups = 1;
+    int nsplit_of[parrm_nmcore::kMaxBatch + 1], groups_of[parrm_nmcore::kMaxBatch + 1];
+};
+ChainPlan chain_plan(int64_t n_idx, int64_t n_chans, int bw) {
+    ChainPlan c;
+    c.nsplit_of[0] = 1;
+    c.groups_of[0] = 0;
+    for (int P = 1; P <= parrm_nmcore::kMaxBatch; ++P) {
+        const FitGeom g = fit_geometry(n_idx, n_chans, P, bw);
+        if (P == 1) c.widest = g;
+        c.nsplit_of[P] = g.nsplit;
+        c.groups_of[P] = g.groups;
+        c.max_nsplit = std::max(c.max_nsplit, g.nsplit);
+        c.max_groups = std::max(c.max_groups, g.groups);
+        c.w_bytes = std::max(c.w_bytes, g.w_bytes);
+        c.part_bytes = std::max(c.part_bytes, g.part_bytes);
+        c.red_bytes = std::max(c.red_bytes, static_cast<size_t>(P) * g.nz * g.elems * sizeof(double));
+    }
+    return c;
+}
+constexpr size_t kChainStateBytes = (sizeof(NmChainState) + 255) / 256 * 256;
+constexpr size_t kChainTableBytes = static_cast<size_t>(kChainTable) * 16;
+bool chain_shape_ok(int64_t n_idx, int64_t n_chans, int bw) {
+    const int K = 2 * bw + 1;
+    return n_idx > 0 && n_idx < (int64_t{1} << 30) && n_chans > 0 && n_chans < (int64_t{1} << 24) && bw >= 0 && bw <= kMaxBw &&
+           (K == 11 || K == 21 || K == 41) && packed_form(bw);
+}
+}  // namespace
+
+size_t nm_chain_workspace_bytes(int64_t n_idx, int64_t n_chans, int bw) {
+    if (!chain_shape_ok(n_idx, n_chans, bw)) return 0;
+    const ChainPlan c = chain_plan(n_idx, n_chans, bw);
+    return c.w_bytes + c.part_bytes + c.red_bytes + 256 * sizeof(double) + kChainStateBytes + kChainTableBytes + 512;
+}
+
+// Runs the refinement `init` describes (a fresh parrm_nmcore::Core: no step taken, nothing known) to its end on the
+// device.  *handled = false (with PARRM_OK): the shape is not one the chain takes, or the device gave up (history or
+// table full) -- the caller steps the refinement from the host instead.  On success the recorded batches are in
+// hist_x / hist_f / batch_sizes and the runs' results in res_*.
+int nm_chain_run(const parrm_nmcore::Core &init, const double *d_y, int64_t ldy, const int64_t *d_idx, int64_t n_idx,
+                 int64_t n_chans, int bw, double lambda, void *d_workspace, size_t workspace_bytes, void *stream, double *hist_x,
+                 double *hist_f, int hist_capacity, int *batch_sizes, int batch_capacity, int *n_batches, int *hist_used,
+                 double *res_x, double *res_f, int *res_its, int *res_calls, bool *handled) {
+    *handled = false;
+    // Opt-in (PARRM_NM_CHAIN=1).  Built in round 4 to take the host out of the loop between two optimiser batches and
+    // measured in the bench step against the host-stepped loop (profiles/r04_nm_chain_ab.txt): the same kernels, the
+    // same bits, and 0.65 ms SLOWER per find_period -- the step kernel that replaces the hand-off takes 10-15 us (a
+    // launch, two dependent trips to L2 for the state and the errors, the state machine, the write-back) against the
+    // 12-16 us the host needs to see the flag, decide and launch; each refinement also pays ~50 us of set-up and two
+    // batch groups that drain as no-ops.  The hand-off was not the lever: the chain's time is its kernels.
+    const char *chain_env = getenv("PARRM_NM_CHAIN");
+    if (!chain_env || atoi(chain_env) == 0 || getenv("PARRM_NM_HOST_STEPPED") || !chain_shape_ok(n_idx, n_chans, bw)) return PARRM_OK;
+    if (init.n_runs < 1 || init.n_runs > parrm_nmcore::kMaxRuns || exact_trig_mode()) return PARRM_OK;
+    const char *accum_env = getenv("PARRM_FIT_ACCUM");
+    if (accum_env && atoi(accum_env) == 1) return PARRM_OK;
+    const ChainPlan plan = chain_plan(n_idx, n_chans, bw);
+    const FitGeom &g = plan.widest;
+    const bool mfma_ok = ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 && n_idx * ldy * 8 < 0x7fff0000LL &&
+                         static_cast<int64_t>(g.n_pad) * 48 * 8 * 3 < 0x7fff0000LL;
+    if (!mfma_ok || static_cast<int64_t>(parrm_nmcore::kMaxBatch) * g.nz > 65535) return PARRM_OK;
+    const size_t need = nm_chain_workspace_bytes(n_idx, n_chans, bw);
+    if (workspace_bytes < need) return PARRM_OK;
+    int dev = 0;
+    PARRM_HIP_CHECK(hipGetDevice(&dev));
+    HostStage &hs = thread_stage();
+    if (!hs.ready(dev) || !hs.chain_ready()) return PARRM_OK;
+    hipStream_t s = as_stream(stream);
+
+    // workspace: design matrices | partial blocks | reduced blocks | errors | state | table
+    char *ws = static_cast<char *>(d_workspace);
+    double *wmat = reinterpret_cast<double *>(ws);
+    double *part = reinterpret_cast<double *>(ws + plan.w_bytes);
+    double *red = reinterpret_cast<double *>(ws + plan.w_bytes + plan.part_bytes);
+    double *d_err = reinterpret_cast<double *>(ws + plan.w_bytes + plan.part_bytes + plan.red_bytes);
+    char *tail = ws + plan.w_bytes + plan.part_bytes + plan.red_bytes + 256 * sizeof(double);
+    tail = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(tail) + 255) & ~uintptr_t{255});
+    NmChainState *d_state = reinterpret_cast<NmChainState *>(tail);
+    unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(tail + kChainStateBytes);
+    double *d_vals = reinterpret_cast<double *>(tail + kChainStateBytes + static_cast<size_t>(kChainTable) * 8);
+
+    NmChainHost *h = hs.h_chain;
+    const long long run_id = ++hs.chain_runs;
+    h->status = 0;
+    NmChainState &st0 = h->init;
+    std::memset(&st0, 0, sizeof st0);
+    st0.core = init;
+    st0.status = kChainRunning;
+    st0.nsplit = 1;
+    std::memcpy(st0.nsplit_of, plan.nsplit_of, sizeof plan.nsplit_of);
+    std::memcpy(st0.groups_of, plan.groups_of, sizeof plan.groups_of);
+    std::atomic_thread_fence(std::memory_order_release);  // (the first step kernel reads the block through its device mapping)
+
+    const int n = static_cast<int>(n_idx), C = static_cast<int>(n_chans), K = 2 * bw + 1;
+    const bool wide = C > 64 && !(C <= 128 && g.nz == 1 && !getenv("PARRM_FIT_NO_TWO_WAVES"));
+    const bool fused = wide && !getenv("PARRM_FIT_UNFUSED");
+    const bool narrow_ok = !getenv("PARRM_FIT_NO_NARROW16");
+    const bool quarters = K == 41 && 4 * g.nz <= 65535 && !getenv("PARRM_FIT_SOLVE_ONE_WORKGROUP");
+    if (fused) {
+        static std::atomic<bool> lds_allowed[64];
+        if (dev < 0 || dev >= 64 || !lds_allowed[dev].load(std::memory_order_acquire)) {
+            PARRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nm_chain_fused_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLdsBytes));
+            if (dev >= 0 && dev < 64) lds_allowed[dev].store(true, std::memory_order_release);
+        }
+    }
+    // The largest batch THIS refinement can form: 2 abscissae per run at the start, 3 per run in flight afterwards, plus
+    // 6 of look-ahead for each of at most `lookahead_runs` runs (expansion / shrink follow-ups are smaller).  The grids
+    // are cut for it, not for kMaxBatch: blocks beyond a batch's geometry return at once, but dispatching them is not
+    // free (measured with grids for 32 candidates: +18 us per Gram launch of 9).
+    const int la = std::max(0, std::min(init.n_runs, init.lookahead_runs));
+    const int Pmax = std::min(parrm_nmcore::kMaxBatch, std::max(3 * init.n_runs, 9 * la));
+    int max_nsplit = 1, max_groups = 1, max_blocks = 1;
+    for (int P = 1; P <= Pmax; ++P) {
+        max_nsplit = std::max(max_nsplit, plan.nsplit_of[P]);
+        max_groups = std::max(max_groups, plan.groups_of[P]);
+        max_blocks = std::max(max_blocks, plan.nsplit_of[P] * plan.groups_of[P]);
+    }
+    const dim3 gram_grid(max_blocks, 1, g.nz);  // (see chain_gram_block)
+    unsigned long long seq = hs.seq;  // (the progress word only ever grows: shared numbering with the publish flag's)
+    auto launch_step = [&](int first) {
+        ++seq;
+        hipLaunchKernelGGL(nm_chain_step_kernel, dim3(1), dim3(64), 0, s, d_state, d_keys, d_vals, part, red, d_err, g.KP, g.nz, C,
+                           quarters ? 1 : 0, hs.d_chain, seq, run_id, first, Pmax);
+        return hipGetLastError();
+    };
+    auto launch_batch = [&]() -> hipError_t {
+        if (fused) {
+            hipLaunchKernelGGL(nm_chain_fused_kernel, gram_grid, dim3(256), kFusedLdsBytes, s, d_state, d_y, ldy, d_idx, g.n_pad, n,
+                               C, g.KP, part, K);
+        } else {
+            hipLaunchKernelGGL(nm_chain_trig_kernel, dim3((g.n_pad + 63) / 64, max_groups), dim3(64 * packed_trig_waves(K)), 0,
+                               s, d_state, d_idx, n, g.n_pad, bw, wmat);
+            if (C <= 16 && narrow_ok)
+                hipLaunchKernelGGL((nm_chain_accum_kernel<1, 1>), gram_grid, dim3(64), 0, s, d_state, d_y, ldy, wmat, g.n_pad, n, C,
+                                   g.KP, part, K);
+            else if (C <= 32 && narrow_ok)
+                hipLaunchKernelGGL((nm_chain_accum_kernel<1, 2>), gram_grid, dim3(64), 0, s, d_state, d_y, ldy, wmat, g.n_pad, n, C,
+                                   g.KP, part, K);
+            else if (C <= 64)
+                hipLaunchKernelGGL((nm_chain_accum_kernel<1, 4>), gram_grid, dim3(64), 0, s, d_state, d_y, ldy, wmat, g.n_pad, n, C,
+                                   g.KP, part, K);
+            else if (C <= 128 && g.nz == 1 && !getenv("PARRM_FIT_NO_TWO_WAVES"))
+                hipLaunchKernelGGL((nm_chain_accum_kernel<2, 4>), gram_grid, dim3(128), 0, s, d_state, d_y, ldy, wmat, g.n_pad, n,
+                                   C, g.KP, part, K);
+            else
+                hipLaunchKernelGGL((nm_chain_accum_kernel<4, 4>), gram_grid, dim3(256), 0, s, d_state, d_y, ldy, wmat, g.n_pad, n,
+                                   C, g.KP, part, K);
+        }
+        if (max_nsplit > 1)
+            hipLaunchKernelGGL(nm_chain_reduce_kernel, dim3(static_cast<unsigned>((g.elems + 255) / 256), Pmax * g.nz), dim3(256), 0,
+                               s, d_state, part, g.elems, g.nz, C, red, K);
+        if (quarters) {
+            hipLaunchKernelGGL((nm_chain_solve_kernel<41, 1>), dim3(Pmax, 4 * g.nz), dim3(64), 0, s, d_state, part, red, n, C, g.KP,
+                               g.nz, lambda, d_err);
+        } else if (K == 41) {
+            hipLaunchKernelGGL((nm_chain_solve_kernel<41, 4>), dim3(Pmax), dim3(256), 0, s, d_state, part, red, n, C, g.KP, g.nz,
+                               lambda, d_err);
+        } else if (K == 21) {
+            hipLaunchKernelGGL((nm_chain_solve_kernel<21, 4>), dim3(Pmax), dim3(256), 0, s, d_state, part, red, n, C, g.KP, g.nz,
+                               lambda, d_err);
+        } else {
+            hipLaunchKernelGGL((nm_chain_solve_kernel<11, 4>), dim3(Pmax), dim3(256), 0, s, d_state, part, red, n, C, g.KP, g.nz,
+                               lambda, d_err);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_step(0);
+    };
+    // batches queued beyond the one the device is working on: the host's ~15 us per batch (4 launches) must stay ahead
+    // of the device's 50-170 us; what is still queued when the refinement ends drains in ~3 us per kernel
+    int ahead = 2;
+    if (const char *env = getenv("PARRM_NM_CHAIN_AHEAD")) ahead = std::max(1, std::min(16, atoi(env)));
+    const unsigned long long base = seq;
+    hipError_t e = launch_step(1);
+    if (e != hipSuccess) {
+        hs.seq = seq;
+        return hip_fail(e, "nm_chain: launch");
+    }
+    // Batch group k = the kernels of batch k and the step kernel that closes it and forms batch k + 1; everything is
+    // stream-ordered, so groups are queued before the state they will read exists.
+    long long queued = 0;
+    unsigned spins = 0;
+    int rc = PARRM_OK;
+    while (true) {
+        if ((h->status >> 8) == run_id) break;
+        const unsigned long long progress = h->progress;
+        const long long steps_done = progress > base ? static_cast<long long>(progress - base) : 0;  // step kernels that ran
+        if (queued < steps_done + ahead) {
+            e = launch_batch();
+            if (e != hipSuccess) {
+                rc = hip_fail(e, "nm_chain: launch");
+                break;
+            }
+            ++queued;
+            continue;
+        }
+        if ((++spins & 0xffff) == 0) {  // look at the stream now and then so that a failed launch cannot hang us
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                rc = hip_fail(q, "nm_chain: stream");
+                break;
+            }
+            if (q == hipSuccess) {  // every queued step kernel has run: its words are visible now or never
+                if ((h->status >> 8) == run_id) break;
+                if (h->progress == progress) {
+                    set_error("nm_chain: the stream drained without progress");
+                    rc = PARRM_ERR_HIP;
+                    break;
+                }
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    hs.seq = seq;
+    if (rc != PARRM_OK) return rc;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if ((h->status & 0xff) != kChainFinished) return PARRM_OK;  // the device gave up: *handled stays false
+    const int nb = h->n_batches, used = h->hist_used;
+    if (nb > batch_capacity || used > hist_capacity) return PARRM_OK;
+    std::memcpy(hist_x, const_cast<const double *>(h->hist_x), static_cast<size_t>(used) * sizeof(double));
+    std::memcpy(hist_f, const_cast<const double *>(h->hist_f), static_cast<size_t>(used) * sizeof(double));
+    std::memcpy(batch_sizes, const_cast<const int *>(h->batch_sizes), static_cast<size_t>(nb) * sizeof(int));
+    for (int r = 0; r < init.n_runs; ++r) {
+        res_x[r] = h->res_x[r];
+        res_f[r] = h->res_f[r];
+        res_its[r] = h->res_its[r];
+        res_calls[r] = h->res_calls[r];
+    }
+    *n_batches = nb;
+    *hist_used = used;
+    *handled = true;
+    return PARRM_OK;
+}
+
+}  // namespace parrm

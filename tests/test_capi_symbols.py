@@ -25,7 +25,7 @@ def test_library_exports_every_symbol():
     lib = _hip.lib()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.parrm_hip_abi_version() == 2
+    assert lib.parrm_hip_abi_version() == 3
     assert lib.parrm_hip_shutdown() == 0  # nothing allocated yet: a no-op that must not need a GPU
     n = ctypes.c_int(-1)
     assert lib.parrm_hip_device_count(ctypes.byref(n)) == 0 and n.value >= 0

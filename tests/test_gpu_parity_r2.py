@@ -992,27 +992,63 @@ def test_fused_gram_kernel_returns_the_two_kernel_forms_bits(monkeypatch, n_chan
 
 
 @pytest.mark.gpu
-def test_refinement_inside_the_library_equals_the_python_stepping(monkeypatch):
-    """``parrm_nm_minimise_fit`` (the whole Nelder-Mead refinement of a stage in one C call, csrc/parrm_nm.hip) against
-    the same refinement stepped through ``pyparrm_amd/_neldermead.py`` (``PARRM_NM_PYTHON=1``'s path): the same batches
-    of abscissae with the same errors, stage by stage and in the final polish, and so the same period -- on a
-    multi-channel recording with five starts per stage and on a short single-channel one."""
+@pytest.mark.parametrize("n_chans,n_samples,seed", [(6, 400_000, 3), (1, 60_000, 4), (70, 120_000, 5), (130, 90_000, 6),
+                                                    (256, 60_000, 7), (300, 40_000, 8)])
+def test_refinement_inside_the_library_equals_the_python_stepping(monkeypatch, n_chans, n_samples, seed):
+    """``parrm_nm_minimise_fit`` (the whole Nelder-Mead refinement of a stage in one C call, csrc/parrm_nm.hip) in its
+    two forms -- one ``parrm_fit_errors_host`` call per batch (the default) and the DEVICE-SIDE CHAIN (round 4,
+    ``PARRM_NM_CHAIN=1``: the device carries the state machine from batch to batch, ``nm_chain_step_kernel``; the host
+    replays and checks) -- against the same refinement stepped through ``pyparrm_amd/_neldermead.py``
+    (``PARRM_NM_PYTHON=1``'s path): the same batches of abscissae with the same errors, stage by stage and in the final
+    polish, and so the same period.  Channel counts pick every Gram kernel form: one wave (<= 16, <= 64 columns), two
+    waves (<= 128), the fused 256-column kernel, more than one column block."""
     from pyparrm_amd import parrm as facade
 
-    for n_chans, n_samples, seed in ((6, 400_000, 3), (1, 60_000, 4)):
-        x = synth_recording_exact(n_chans, n_samples, 22000.0 / 130.0 * (1 + 2e-4), seed)
-        traces = []
-        for in_python in (False, True):
-            monkeypatch.setattr(facade, "_NM_IN_PYTHON", in_python)
-            p = PARRM(x, 22000.0, 130.0, verbose=False)
-            p.find_period(random_seed=9)
-            traces.append((p.period, p._trace))
-        (period_a, trace_a), (period_b, trace_b) = traces
-        assert period_a == period_b
-        for ta, tb in zip(trace_a, trace_b):
+    x = synth_recording_exact(n_chans, n_samples, 22000.0 / 130.0 * (1 + 2e-4), seed)
+    traces = []
+    for mode in ("chain", "host_stepped", "python"):
+        monkeypatch.setattr(facade, "_NM_IN_PYTHON", mode == "python")
+        if mode == "chain":
+            monkeypatch.setenv("PARRM_NM_CHAIN", "1")
+        else:
+            monkeypatch.delenv("PARRM_NM_CHAIN", raising=False)
+        p = PARRM(x, 22000.0, 130.0, verbose=False)
+        p.find_period(random_seed=9)
+        traces.append((p.period, p._trace))
+    period_py, trace_py = traces[2]
+    for mode, (period, trace) in zip(("chain", "host_stepped"), traces[:2]):
+        assert period == period_py, mode
+        for ta, tb in zip(trace, trace_py):
             for key in ("refine_evals", "final_evals"):
                 if key not in ta:
                     continue
-                assert len(ta[key]) == len(tb[key]) > 0, key
+                assert len(ta[key]) == len(tb[key]) > 0, (mode, key)
                 for (pa, ea), (pb, eb) in zip(ta[key], tb[key]):
-                    assert np.array_equal(pa, pb) and np.array_equal(ea, eb), key
+                    assert np.array_equal(pa, pb) and np.array_equal(ea, eb), (mode, key)
+
+
+@pytest.mark.gpu
+def test_device_side_refinement_runs_when_asked_for_and_only_then(monkeypatch):
+    """``PARRM_NM_CHAIN=1`` really runs the refinements as device-side chains (not a silent fall-back to the
+    host-stepped loop) and the default really is the host-stepped loop: ``parrm_nm_chain_stats`` counts the refinements
+    of each form and the batches the device stepped through on its own."""
+    import ctypes as C
+
+    x = synth_recording_exact(256, 80_000, 22000.0 / 130.0 * (1 - 1e-4), 12)
+    stats = (C.c_longlong * 4)()
+
+    def run():
+        _hip.lib().parrm_nm_chain_stats(stats)
+        before = list(stats)
+        p = PARRM(x, 22000.0, 130.0, verbose=False)
+        p.find_period(random_seed=2)
+        _hip.lib().parrm_nm_chain_stats(stats)
+        return p.period, [a - b for a, b in zip(stats, before)]
+
+    monkeypatch.delenv("PARRM_NM_CHAIN", raising=False)
+    period_default, d = run()
+    assert d[0] == 0 and d[1] == 4 and d[3] >= 40, d       # three stages + the final polish, stepped from the host
+    monkeypatch.setenv("PARRM_NM_CHAIN", "1")
+    period_chain, d = run()
+    assert d[0] == 4 and d[1] == 0 and d[2] >= 40, d       # the same four refinements as device-side chains
+    assert period_chain == period_default

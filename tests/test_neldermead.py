@@ -75,11 +75,15 @@ def test_maxfun_termination_matches_scipy():
     assert got[0][0] == ref[0][0] and got[1] == ref[1] and got[3] == ref[3]
 
 
-def test_native_neldermead_equals_the_python_generator():
+@pytest.mark.parametrize("engine", ["NativeNelderMead", "NelderMeadCoreOnHost"])
+def test_native_neldermead_equals_the_python_generator(engine):
     """csrc/parrm_nm.hip (the refinement inside the C library: ``parrm_nm_next`` / ``parrm_nm_feed``, and through them
     ``parrm_nm_minimise_fit``) against ``fmin_lockstep_requests``: the same batches of abscissae in the same order and
     the same (xopt, fopt, iterations, funcalls) on 400 random problems -- smooth, rough, NaN plateaus, runs that end on
-    maxiter / maxfun, exact ties, a zero start, one to five starts, random tolerances.  Needs no GPU."""
+    maxiter / maxfun, exact ties, a zero start, one to five starts, random tolerances.  Needs no GPU.
+
+    ``NelderMeadCoreOnHost``: the same for ``csrc/parrm_nm_core.h``, the plain-data restatement of that state machine
+    which the DEVICE runs between two optimiser batches (``nm_chain_step_kernel``), compiled for the host."""
     from pyparrm_amd import _hip
     from pyparrm_amd._neldermead import fmin_lockstep_requests
 
@@ -106,7 +110,7 @@ def test_native_neldermead_equals_the_python_generator():
         if case % 11 == 0:
             kw.update(maxiter=int(rng.integers(1, 30)), maxfun=int(rng.integers(2, 40)))
         steps = fmin_lockstep_requests(starts, kw["xtol"], kw["ftol"], kw.get("maxiter"), kw.get("maxfun"))
-        native = _hip.NativeNelderMead(starts, **kw)
+        native = getattr(_hip, engine)(starts, **kw)
         try:
             points = next(steps)
             while True:
