@@ -478,6 +478,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
+                                   "scripts/profile_filter.py on this kernel and shape (FETCH_SIZE x 2, the gfx950 correction); "
+                                   "a tracked measurement, NOT collected in this run") if traffic is not None else None,
                 "launch_ms": kern_s * 1e3,
                 "rows_per_launch": rows,
             },
@@ -494,7 +497,10 @@ def main():
             flops = float(np.mean([sum(g[1] for g in gs) for gs in timings["grids"]]))
             out["roofline_find_period"] = {
                 "kernel": "fit_accum_fused_kernel (bracket = one grid call: design rows + Gram blocks in one kernel, reduction, solves)",
-                "bound": "fp64-mfma", "flops": flops, "ms_per_step": per_step_ms,
+                "bound": "fp64-mfma (deliberate: north_star says 'no MFMA', but the candidate grids are a dense float64 "
+                         "contraction W'[Y W] -- SURVEY.md 7 hard part 4 -- and run on the matrix cores; filter_data, the "
+                         "bandwidth-bound part, uses none)",
+                "flops": flops, "ms_per_step": per_step_ms,
                 "achieved": flops / per_step_ms / 1e9, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / per_step_ms / 1e9 / 78.6,
                 "grids": [{"candidates": g[2], "K": g[3], "ms": g[0]} for g in timings["grids"][-1]],
                 "note": "algorithmic flops 2 n K (C + K) per candidate (SURVEY.md 8d); Nelder-Mead batches are not in the bracket",
@@ -511,6 +517,14 @@ def main():
             def kernel_name(pl):
                 return "parrm_comb_kernel (generated)" if pl.generated[0] == 1 else "filter_phase_kernel"
 
+            # the box's own copy rate on the headline launch's buffers, in this process: torch's vectorised device copy
+            # moves the same 16 B/sample (read 8, write 8) -- the roofline fraction against the 8 TB/s spec says how far
+            # the kernel is from the data sheet, this one how far it is from what THIS box copies at
+            y_copy = torch.empty_like(x)
+            ms_copy = launch_ms(lambda: y_copy.copy_(x), 3)
+            del y_copy
+            out["roofline"]["copy_ms_same_box"] = ms_copy
+            out["roofline"]["frac_of_copy_rate"] = ms_copy / (kern_s * 1e3)
             x2 = x[:64, :1_000_000].contiguous()
             y2 = torch.empty_like(x2)
             ms2 = launch_ms(lambda: plan.apply(x2, out=y2))

@@ -22,6 +22,26 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (dev >= 0 && dev < 64) {
+        const int c = cached[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (dev >= 0 && dev < 64) cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 int hip_fail(hipError_t err, const char *what) {
     set_error("%s: %s (%s)", what, hipGetErrorString(err), hipGetErrorName(err));
     return err == hipErrorNoDevice ? PARRM_ERR_NO_DEVICE : PARRM_ERR_HIP;

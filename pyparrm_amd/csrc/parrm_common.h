@@ -16,6 +16,12 @@ int hip_fail(hipError_t err, const char *what);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the CURRENT device (hipDeviceProp_t::multiProcessorCount, cached per device): 256 on a whole MI355X,
+// fewer on a partitioned one (CPX / NPS modes expose a slice of the chip per device).  What the launch planners size
+// their rounds of resident workgroups by.  256 when no device can be queried (the planners also run on GPU-less hosts:
+// workspace sizes, the build-time kernel generator).
+int device_cu_count();
+
 // 64-lane wavefront sum, result valid in every lane (fixed butterfly order -> deterministic).
 __device__ inline double wave_sum(double v) {
 #pragma unroll

@@ -202,6 +202,9 @@ class Emitter {
         // its own code object.
         if (const char *e = getenv("PARRM_COMB_DEBUG")) debug_ = atoi(e);
         if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0 && !in32 && !out32;
+        // cache policy of the once-read row requests (bit 0) and the once-written output stores (bit 1): `nt`
+        // (part of the source text, like the ablations: every setting is a code object of its own)
+        if (const char *e = getenv("PARRM_COMB_NT")) nt_ = atoi(e);
     }
 
     // (base register, immediate) of element `col` of ring row m - a for lane row r, at ring phase km
@@ -354,8 +357,8 @@ class Emitter {
             const int ix = 2 * r;
             s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n";
             if (debug_ & 2) s << "          asm volatile(\"\" :: \"v\"(yv));\n";
-            else if (out32_) s << "          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, (float)yv), rsrc_y, yoff, " << r * g_.q * 4 << "u, 0);\n";
-            else s << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, 0);\n";
+            else if (out32_) s << "          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, (float)yv), rsrc_y, yoff, " << r * g_.q * 4 << "u, " << ((nt_ & 2) ? 2 : 0) << ");\n";
+            else s << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, " << ((nt_ & 2) ? 2 : 0) << ");\n";
             s << "          S += eb" << ix + 1 << "; }\n";
             compute.push_back(s.str());
         }
@@ -419,7 +422,7 @@ class Emitter {
         const int n = g_.nld;
         // (float32 rows: 8-byte requests at 4-byte aligned addresses -- fine for buffer loads, checked on gfx950)
         for (int i = 0; i < n; ++i)
-            o << "\"" << (in32_ ? "buffer_load_dwordx2" : "buffer_load_dwordx4") << " %" << i << ", %" << n + i << ", %" << 2 * n << ", %" << 2 * n + 1 << " offen\\n\\t\"\n                         ";
+            o << "\"" << (in32_ ? "buffer_load_dwordx2" : "buffer_load_dwordx4") << " %" << i << ", %" << n + i << ", %" << 2 * n << ", %" << 2 * n + 1 << " offen" << ((nt_ & 1) ? " nt" : "") << "\\n\\t\"\n                         ";
         o << "\"\"\n                         :";
         for (int i = 0; i < n; ++i) o << (i ? ", " : " ") << "\"=&v\"(pf" << set << "_" << i << ")";
         o << "\n                         :";
@@ -731,6 +734,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) KNAME(CombArgs a) {
     const Geom &g_;
     int batch_;
     int debug_ = 0;
+    int nt_ = 0;
     bool wide_b_ = false;  // stage B: two residues per lane, 16-byte reads and stores
     bool in32_ = false, out32_ = false;  // float32 recording (widened to float64 on its way into the ring) / float32 output
 };
@@ -950,7 +954,7 @@ int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw) {
 int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     FilterArgs &a = *args;
     const Geom &g = k->geom;
-    // Stretch length: one workgroup per CU (256 resident); a stretch costs its rows plus a prologue of
+    // Stretch length: one workgroup per CU (256 resident on a whole MI355X); a stretch costs its rows plus a prologue of
     // a_hi - a_lo + 2 NR rows and one tap-by-tap evaluation (~ 5 rows' worth).  Long recordings: ~1 M samples.
     const int64_t q = g.q;
     const int64_t prologue_rows = g.a_hi - g.a_lo + 2 * kNR + 8;
@@ -964,7 +968,7 @@ int launch_comb(const CombKernel *k, FilterArgs *args, hipStream_t stream) {
     int64_t rows = std::max<int64_t>(kNR, (((a.out_len + n_cut - 1) / n_cut + q - 1) / q + kNR - 1) / kNR * kNR);
     auto blocks_for = [&](int64_t r) { return a.plan_chans * ((a.out_len + r * q - 1) / (r * q)); };
     if (blocks_for(rows) < 2048 && !getenv("PARRM_COMB_STRETCH")) {
-        const int64_t resident = 256;
+        const int64_t resident = parrm::device_cu_count();  // one workgroup per CU (141 KB of LDS)
         double best = 1e300;
         int64_t best_rows = rows;
         const int64_t max_stretches = std::max<int64_t>(1, a.out_len / (static_cast<int64_t>(4) * kNR * q));

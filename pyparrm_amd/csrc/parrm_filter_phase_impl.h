@@ -977,7 +977,7 @@ static int launch_phase_r(const parrm_filter_plan *plan, FilterArgs *args, Phase
     auto blocks_for = [&](int64_t r) { return a.plan_chans * ((a.out_len + r * g.q - 1) / (r * g.q)); };
     if (blocks_for(rows) < 4096 && !getenv("PARRM_STRETCH_SAMPLES")) {
         const double prologue = 16384.0;
-        const int64_t resident = 512;
+        const int64_t resident = 2 * static_cast<int64_t>(parrm::device_cu_count());  // two workgroups per CU
         double best = 1e300;
         int64_t best_rows = rows;
         const int64_t max_stretches = std::max<int64_t>(1, a.out_len / (static_cast<int64_t>(4) * ngr * g.q));

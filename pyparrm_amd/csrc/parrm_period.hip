@@ -1611,7 +1611,7 @@ FitGeom fit_geometry(int64_t n_idx, int64_t n_chans, int64_t n_periods, int bw, 
     // microseconds: a whole-length workgroup takes ~0.2 us per sample at 12 MFMAs per wave and step (256 columns;
     // the one-wave forms for <= 16 / <= 32 columns a quarter / half of that).  Never below 4 tiles per slice.
     const int64_t max_split = std::max<int64_t>(1, std::min<int64_t>(64, (tiles + 3) / 4));
-    const int64_t resident = n_chans <= 64 ? 1024 : 512;  // one-wave workgroups (<= 64 channels): four per CU
+    const int64_t resident = static_cast<int64_t>(parrm::device_cu_count()) * (n_chans <= 64 ? 4 : 2);  // one-wave workgroups (<= 64 channels): four per CU, else two (512 on a whole MI355X)
     const double t_full = 0.2 * static_cast<double>(g.n_pad) * (n_chans <= 16 ? 0.25 : (n_chans <= 32 ? 0.5 : 1.0));
     const int64_t plan_p = std::max(plan_periods, n_periods);
     const double cols_used = static_cast<double>(std::min<int64_t>(n_chans, kYCols) + 64);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Interleaved A/B of generated-comb-kernel variants on one device: every arm is a set of NAME=VALUE settings in
 force while ITS plan is built and launched (generator knobs are read when the kernel is generated, i.e. at the
-plan's first large launch).  `phase` as an arm name = the phase-major kernel (PARRM_COMB=0).
+plan's first large launch).  `phase` as an arm name = the phase-major kernel (PARRM_COMB=0); `copy` = a plain device copy of the recording into the
+output (torch's vectorised copy kernel: the same 16 B/sample, the box's copy ceiling in the same process).
 
     python scripts/ab_comb.py default PARRM_COMB_DEBUG=1 PARRM_COMB_BATCH=5,PARRM_COMB_STRETCH=524288 phase
 """
@@ -49,6 +50,18 @@ def main():
     times = {a: [] for a in args.arms}
     for rnd in range(args.rounds + 1):
         for arm in args.arms:
+            if arm == "copy":
+                y.copy_(x)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    y.copy_(x)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    times[arm].append(e0.elapsed_time(e1) / 3)
+                continue
             env = settings(arm)
             os.environ.update(env)
             if arm not in plans:
