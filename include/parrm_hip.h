@@ -223,6 +223,14 @@ int parrm_filter_kernel_timing(int enable, float *last_ms);
  * -1 = not available for this filter (message says why; the generic kernels run instead). */
 int parrm_filter_plan_generated(const parrm_filter_plan *plan, int *state, int *stride, char *message,
                                 size_t message_len);
+/* Background mode: a plan whose generated kernel has to be COMPILED (no cached code object; ~1.7 s of hipRTC) hands
+ * the build -- compile, load, spill check, self-test -- to a worker thread at the first large launch and serves that
+ * launch and the following ones from the generic kernels (same results within the parity bar) until the kernel has
+ * passed its self-test; parrm_filter_plan_generated then reports state 2 meanwhile.  For callers that re-filter
+ * interactively with ever new filters (the reference's parameter explorer, _utils/_plotting.py:568-584).  Off by
+ * default: a channel-sharded run wants every block filtered by the same kernel (bit-identical to the one-device
+ * result), which a swap in mid-run would break.  parrm_filter_plan_destroy waits for a build in flight. */
+int parrm_filter_plan_set_background(parrm_filter_plan *plan, int on);
 int parrm_filter_comb_precompile(const double *h_filter, int64_t filter_len, int64_t stride,
                                  const char *out_dir, char *source_path, size_t source_path_len);
 

@@ -36,6 +36,7 @@ SYMBOLS = (
     "parrm_filter_host",
     "parrm_filter_comb_precompile",
     "parrm_filter_plan_generated",
+    "parrm_filter_plan_set_background",
     "parrm_filter_kernel_timing",
     "parrm_host_pin",
     "parrm_host_unpin",
@@ -165,6 +166,8 @@ def lib() -> C.CDLL:
         L.parrm_filter_plan_set_kernel.restype = i32
         L.parrm_filter_plan_set_kernel.argtypes = [vp, i32]
         L.parrm_filter_plan_generated.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+        L.parrm_filter_plan_set_background.restype = i32
+        L.parrm_filter_plan_set_background.argtypes = [vp, i32]
         L.parrm_filter_kernel_timing.argtypes = [i32, C.POINTER(C.c_float)]
         L.parrm_filter_comb_precompile.argtypes = [vp, i64, i64, C.c_char_p, C.c_char_p, C.c_size_t]
         L.parrm_filter_apply.restype = i32
@@ -382,6 +385,22 @@ class FilterPlan:
 
     def set_kernel(self, kernel: int) -> None:
         check(lib().parrm_filter_plan_set_kernel(self._h, kernel), "parrm_filter_plan_set_kernel")
+
+    def set_background_compile(self, on: bool = True) -> None:
+        """A generated kernel that has to be compiled first (~1.7 s of hipRTC for a geometry nobody has built yet) is
+        built by a worker thread while the generic kernels serve the launches; ``generated`` reports state 2 meanwhile."""
+        check(lib().parrm_filter_plan_set_background(self._h, 1 if on else 0), "parrm_filter_plan_set_background")
+
+    def wait_generated(self, timeout: float = 60.0):
+        """Block until a background build has ended (or ``timeout`` seconds); returns ``generated``."""
+        import time
+
+        t0 = time.monotonic()
+        while True:
+            g = self.generated
+            if g[0] != 2 or time.monotonic() - t0 > timeout:
+                return g
+            time.sleep(0.01)
 
     def apply(self, x, out=None, out_dtype=None, total_chans=None):
         """y = filter(x) for a device-resident recording ``x[C, N]`` (f32/f64).  ``total_chans``: ``x`` is

@@ -306,8 +306,9 @@ std::mutex g_comb_mutex;
 // periods, both ends of the recording included) and compare with the tap-by-tap gather kernel.  The generator is
 // exercised by filters nobody has seen before (tap geometry is the caller's: create_filter's half-widths, omitted
 // samples, direction); a kernel that does not reproduce the direct evaluation is never used.  ~1 ms, once per plan.
+// `stream`: nullptr on the launching thread (first use of a cached kernel), a stream of its own on a worker thread.
 template <typename TI, typename TO>
-bool comb_self_test(const parrm_filter_plan *p, CombKernel *ck) {
+bool comb_self_test(const parrm_filter_plan *p, CombKernel *ck, hipStream_t stream = nullptr) {
     if (getenv("PARRM_COMB_NO_SELFTEST")) return true;
     const int64_t n = 2 * p->hw + 6 * comb_reach(ck) + 12345, c = 2;
     std::vector<TI> h(static_cast<size_t>(c * n));
@@ -323,7 +324,7 @@ bool comb_self_test(const parrm_filter_plan *p, CombKernel *ck) {
     const size_t in_bytes = h.size() * sizeof(TI), out_bytes = h.size() * sizeof(TO);
     hipError_t e = hipMalloc(&d, in_bytes + 2 * out_bytes + 64);
     if (e == hipSuccess) {
-        e = hipMemcpy(d, h.data(), in_bytes, hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(d, h.data(), in_bytes, hipMemcpyHostToDevice, stream);
         FilterArgs a{};
         a.x = d;
         a.n_chans = c;
@@ -341,11 +342,12 @@ bool comb_self_test(const parrm_filter_plan *p, CombKernel *ck) {
         a.y = d + y_off;
         b.y = d + y_off + (out_bytes + 15) / 16 * 16;
         int rc = PARRM_OK;
-        if (e == hipSuccess) rc = launch_comb(ck, &a, nullptr);
-        if (e == hipSuccess && rc == PARRM_OK) rc = launch_main<TI, TO>(p, &b, PARRM_KERNEL_GATHER, nullptr);
+        if (e == hipSuccess) rc = launch_comb(ck, &a, stream);
+        if (e == hipSuccess && rc == PARRM_OK) rc = launch_main<TI, TO>(p, &b, PARRM_KERNEL_GATHER, stream);
         std::vector<TO> y1(h.size()), y2(h.size());
-        if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpy(y1.data(), a.y, out_bytes, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpy(y2.data(), b.y, out_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpyAsync(y1.data(), a.y, out_bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpyAsync(y2.data(), b.y, out_bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess && rc == PARRM_OK) e = hipStreamSynchronize(stream);
         if (e == hipSuccess && rc == PARRM_OK) {
             double worst = 0.0;
             for (size_t i = 0; i < y1.size(); ++i) {
@@ -365,8 +367,42 @@ bool comb_self_test(const parrm_filter_plan *p, CombKernel *ck) {
     } else {
         comb_set_error(ck, "self-test: out of device memory");
     }
-    if (d) (void)hipFree(d);
+    if (d) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(d);
+    }
     return ok;
+}
+
+// Load (compile if need be), refuse spilling builds in favour of leaner ones, self-test: the kernel that may be used,
+// or the last candidate with its error.  Runs on the launching thread (under g_comb_mutex) or on a plan's worker.
+template <typename TI, typename TO>
+int comb_build(const parrm_filter_plan *p, CombKernel *&ck, int64_t q, hipStream_t stream) {
+    constexpr bool in32 = sizeof(TI) == 4, out32 = sizeof(TO) == 4;
+    int state = -1;
+    for (int attempt = 0; ck; ++attempt) {
+        if (comb_load(ck)) {
+            if (comb_self_test<TI, TO>(p, ck, stream)) state = 1;
+            break;
+        }
+        CombKernel *next = strstr(comb_error(ck), "scratch") ? comb_generate(p->tap_mask, p->hw, q, attempt + 1, in32, out32) : nullptr;
+        if (!next) break;
+        comb_destroy(ck);
+        ck = next;
+    }
+    if (ck && state != 1 && getenv("PARRM_COMB_VERBOSE"))
+        fprintf(stderr, "parrm: generated filter kernel unavailable: %s\n", comb_error(ck));
+    return state;
+}
+
+// a finished background build becomes the plan's kernel (g_comb_mutex held)
+inline void comb_adopt(const parrm_filter_plan *p, int v) {
+    std::shared_ptr<CombJob> &job = p->comb_job[v];
+    if (p->comb_state[v] != 2 || !job || !job->done.load(std::memory_order_acquire)) return;
+    if (job->worker.joinable()) job->worker.join();
+    p->comb[v] = job->kernel;
+    p->comb_state[v] = job->result_state;
+    job.reset();
 }
 
 // variant: 0 = float64 -> float64, 1 = float32 -> float64, 2 = float32 -> float32
@@ -395,20 +431,35 @@ const CombKernel *comb_for_launch(const parrm_filter_plan *p, const FilterArgs &
             return nullptr;
         }
         state = -1;
-        // a build that spills registers is refused at load time: leaner variants (smaller read batches) are tried
-        for (int attempt = 0; ck; ++attempt) {
-            if (comb_load(ck)) {
-                if (comb_self_test<TI, TO>(p, ck)) state = 1;
-                break;
-            }
-            CombKernel *next = strstr(comb_error(ck), "scratch") ? comb_generate(p->tap_mask, p->hw, q, attempt + 1, in32, out32) : nullptr;
-            if (!next) break;
-            comb_destroy(ck);
-            ck = next;
+        // A geometry nobody has compiled yet costs ~1.7 s of hipRTC.  A plan in background mode
+        // (parrm_filter_plan_set_background: the facade's unsharded filter_data; the reference's parameter explorer
+        // re-filters on every widget event, _utils/_plotting.py:568-584) hands the build to a worker thread and
+        // serves this and the following launches from the generic kernels -- same results within the parity bar --
+        // until the kernel has passed its self-test.  PARRM_COMB=force and cached code objects stay synchronous.
+        if (ck && p->comb_background && !force && !comb_code_cached(ck)) {
+            auto job = std::make_shared<CombJob>();
+            job->kernel = ck;
+            ck = nullptr;
+            state = 2;
+            p->comb_job[v] = job;
+            const int device = p->device;
+            CombJob *raw = job.get();  // (the plan joins the worker before it goes away: parrm_filter_plan_destroy)
+            job->worker = std::thread([p, raw, q, device]() {
+                hipStream_t st = nullptr;
+                if (hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+                    raw->result_state = comb_build<TI, TO>(p, raw->kernel, q, st);
+                    (void)hipStreamDestroy(st);
+                } else if (raw->kernel) {
+                    comb_set_error(raw->kernel, "background build: no device");
+                }
+                raw->done.store(1, std::memory_order_release);
+            });
+            return nullptr;
         }
-        if (ck && state != 1 && getenv("PARRM_COMB_VERBOSE"))
-            fprintf(stderr, "parrm: generated filter kernel unavailable: %s\n", comb_error(ck));
+        // a build that spills registers is refused at load time: leaner variants (smaller read batches) are tried
+        state = comb_build<TI, TO>(p, ck, q, nullptr);
     }
+    comb_adopt(p, v);
     if (state != 1 || !comb_accepts(ck, a)) return nullptr;
     return ck;
 }
@@ -725,6 +776,12 @@ int parrm_filter_plan_destroy(parrm_filter_plan *plan) {
     if (!plan) return PARRM_OK;
     if (plan->d_weights) (void)hipFree(plan->d_weights);  // the one allocation (weights | tables | phase table)
     for (parrm_filter_plan *sub : plan->segments) (void)parrm_filter_plan_destroy(sub);
+    for (int v = 0; v < 3; ++v)
+        if (plan->comb_job[v]) {  // a background build still uses the plan's tables: wait for it
+            if (plan->comb_job[v]->worker.joinable()) plan->comb_job[v]->worker.join();
+            parrm_filter::comb_destroy(plan->comb_job[v]->kernel);
+            plan->comb_job[v].reset();
+        }
     for (parrm_filter::CombKernel *ck : plan->comb) parrm_filter::comb_destroy(ck);
     delete plan;
     return PARRM_OK;
@@ -756,9 +813,18 @@ int parrm_filter_plan_generated(const parrm_filter_plan *plan, int *state, int *
     PARRM_REQUIRE(plan && state, "filter_plan_generated: NULL argument");
     std::lock_guard<std::mutex> lock(g_comb_mutex);
     const int v = plan->comb_last;  // (the element types of the last launch that asked for a generated kernel)
+    comb_adopt(plan, v);
     *state = plan->comb_state[v];
     if (stride) *stride = plan->comb[v] ? comb_stride(plan->comb[v]) : 0;
-    if (message && message_len) snprintf(message, message_len, "%s", plan->comb[v] ? comb_error(plan->comb[v]) : "");
+    if (message && message_len)
+        snprintf(message, message_len, "%s", *state == 2 ? "being compiled in the background" : plan->comb[v] ? comb_error(plan->comb[v]) : "");
+    return PARRM_OK;
+}
+
+int parrm_filter_plan_set_background(parrm_filter_plan *plan, int on) {
+    PARRM_REQUIRE(plan, "filter_plan_set_background: NULL plan");
+    std::lock_guard<std::mutex> lock(g_comb_mutex);
+    plan->comb_background = on != 0;
     return PARRM_OK;
 }
 

@@ -919,6 +919,13 @@ bool comb_load(CombKernel *k) {
     return true;
 }
 
+bool comb_code_cached(const CombKernel *k) {
+    if (getenv("PARRM_COMB_NO_CACHE")) return false;
+    const std::string name = code_name(k->source);
+    struct stat sb;
+    return stat((library_dir() + "/kernels/" + name).c_str(), &sb) == 0 || stat((user_cache_dir() + "/" + name).c_str(), &sb) == 0;
+}
+
 const char *comb_error(const CombKernel *k) { return k->error.c_str(); }
 void comb_set_error(CombKernel *k, const char *msg) { k->error = msg; }
 int comb_reach(const CombKernel *k) { return (k->geom.a_hi - k->geom.a_lo + 2) * k->geom.q; }

@@ -3,6 +3,10 @@
 
 #include <vector>
 
+#include <atomic>
+#include <memory>
+#include <thread>
+
 #include "parrm_common.h"
 
 namespace parrm_filter {
@@ -159,10 +163,17 @@ struct PhaseGeom {
 namespace parrm_filter {
 // parrm_filter_comb.hip: the per-filter generated kernel (float64 recordings, comb filters with q in [80, 176])
 struct CombKernel;
+struct CombJob {  // one background build (compile, load, spill check, self-test) of a plan's generated kernel
+    std::thread worker;
+    std::atomic<int> done{0};  // set last by the worker: result_state / kernel are final
+    int result_state = -1;     // 1 loaded and verified, -1 unavailable
+    CombKernel *kernel = nullptr;
+};
 CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt = 0, bool in32 = false,
                           bool out32 = false);
 void comb_destroy(CombKernel *k);
 bool comb_load(CombKernel *k);  // code object from the caches or hipRTC, loaded on the current device
+bool comb_code_cached(const CombKernel *k);  // a code object for its source is in the in-tree directory or the user cache
 const char *comb_error(const CombKernel *k);
 void comb_set_error(CombKernel *k, const char *msg);
 int comb_reach(const CombKernel *k);
@@ -202,6 +213,10 @@ struct parrm_filter_plan {
     mutable parrm_filter::CombKernel *comb[3] = {nullptr, nullptr, nullptr};
     mutable int comb_state[3] = {0, 0, 0};
     mutable int comb_last = 0;
+    // comb_state 2 = being compiled by a worker thread (parrm_filter_plan_set_background): launches run the generic
+    // kernels meanwhile; the job's result is adopted by the next launch or query after it has finished
+    bool comb_background = false;
+    mutable std::shared_ptr<parrm_filter::CombJob> comb_job[3];
 };
 
 

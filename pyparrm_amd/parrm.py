@@ -28,9 +28,11 @@ not to modify the array in place, or calls :meth:`PARRM.release_device_cache` af
 from __future__ import annotations
 
 import copy
+import os
 from multiprocessing import cpu_count
 
 import numpy as np
+
 from . import _hip
 from ._neldermead import fmin_lockstep_requests
 
@@ -106,6 +108,11 @@ class PARRM:
 
     #: keep the device copy of a host recording between calls (see the module docstring)
     cache_on_device = False
+    #: a filter whose generated kernel has to be compiled first (~1.7 s of hipRTC for a tap geometry nobody has built
+    #: yet) is filtered by the generic kernels -- same results within the parity bar -- while a worker thread builds
+    #: the generated one: no ``filter_data`` call waits for a compiler (the reference's parameter explorer re-filters
+    #: on every widget event, _utils/_plotting.py:568-584).  False: the first large call compiles, as in round 3.
+    background_compile = True
 
     # device-side state: rebuilt lazily, never copied or pickled (``__deepcopy__`` / ``__getstate__``)
     _DEVICE_STATE = ("_d_data", "_d_data_src", "_d_scale", "_plans", "_last_plan", "_in_call")
@@ -763,6 +770,10 @@ class PARRM:
         plan = self._plans.get(index)
         if plan is None:
             plan = self._plans[index] = _hip.shared_filter_plan(self._filter, index)
+        # (per call: plans are shared between objects with the same filter, and a channel-sharded object must not have
+        # its kernel swapped in mid-run)
+        plan.set_background_compile(self.background_compile and type(self)._total_chans is PARRM._total_chans
+                                    and os.environ.get("PARRM_COMB_ASYNC", "1") != "0")
         self._last_plan = plan
         return plan
 
