@@ -562,6 +562,17 @@ int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStr
         PARRM_HIP_CHECK(hipGetLastError());
         return PARRM_OK;
     }
+    // A filter the phase-major kernel does not take (wide teeth: its guard columns end at 6 residues) may still be one
+    // the generated kernel takes (halo up to 40 columns, teeth as sliding sums) -- asked here when the stride kernel
+    // was the plan's own choice, not a caller's (parrm_filter_plan_set_kernel).
+    if (p->forced_kernel == PARRM_KERNEL_AUTO) {
+        if constexpr (sizeof(TI) == 4 && sizeof(TO) == 4) {
+            if (!getenv("PARRM_F32_PACKED"))
+                if (const CombKernel *ck = comb_for_launch<TI, TO>(p, a)) return launch_comb(ck, args, stream);
+        } else {
+            if (const CombKernel *ck = comb_for_launch<TI, TO>(p, a)) return launch_comb(ck, args, stream);
+        }
+    }
     // stride kernel geometry
     const int q = static_cast<int>(p->q);
     const int G = p->rows_per_fill;

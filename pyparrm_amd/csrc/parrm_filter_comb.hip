@@ -62,6 +62,7 @@ namespace {
 constexpr int kNR = 16;       // rows per iteration (4 waves x 4 rows)
 constexpr int kAThreads = 512;  // stage A: two wave sets of four waves (stage B: ceil(q / 64) more waves)
 constexpr int kLdsLimit = 160 * 1024;
+constexpr int kMaxGuard = 40;  // (what fits is decided by the LDS check below: 2 * guard more columns per ring row)
 
 struct Unit {  // one delta element: `width` adjacent taps of one sign in row m - a, offsets b_lo .. b_lo + width - 1
     int a, b_lo, width, sign;
@@ -105,7 +106,7 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
         g->a_lo = std::min(g->a_lo, a);
         g->a_hi = std::max(g->a_hi, a);
     }
-    if (delta.empty() || delta.size() > 96) return false;
+    if (delta.empty() || delta.size() > 256) return false;  // (96 until round 4: two whole 43-wide teeth at the comb's ends are 86 on their own)
     g->n_taps = 0;
     for (int64_t w = -hw; w <= hw; ++w) {
         if (!tap_at(w)) continue;
@@ -115,7 +116,9 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
         g->a_lo = std::min(g->a_lo, a);  // the initialisation reads row -a of the prologue fill
         g->a_hi = std::max(g->a_hi, a);
     }
-    if (guard > 12) return false;
+    // (the halo: 2 * guard more columns per ring row.  12 until round 4; wide teeth -- period_half_width of a tenth of
+    // the period and more -- reach further, and as sliding sums they are cheap: C + w - 1 reads per tooth edge)
+    if (guard > kMaxGuard) return false;
     g->hb = guard;
     // the ring always holds the rows of the current iteration themselves (stage B reads its own samples there), also
     // when every tap lies on one side of the centre (one-sided filters with omitted samples: found by the self-test)
@@ -311,7 +314,14 @@ class Emitter {
                 for (int i = i0; i < i1; ++i) {
                     std::ostringstream s;
                     const int ii = i - i0;
-                    if (ii == 0) {
+                    if (ii == 0 && u.width > 8) {
+                        // a wide tooth (round 4): summed element by element as the reads come back -- the same
+                        // left-to-right order -- so that only the C - 1 elements the sliding update subtracts
+                        // later stay in registers, not all w of them (w = 20 ... 45: the build spilled)
+                        compute[first_read] = "        double " + t + " = " + e(0) + ";\n";
+                        for (int j = 1; j + 1 < u.width; ++j) compute[first_read + j] = "        " + t + " += " + e(j) + ";\n";
+                        s << "        " << t << " += " << e(u.width - 1) << ";\n";
+                    } else if (ii == 0) {
                         s << "        double " << t << " = " << e(0);
                         for (int j = 1; j < u.width; ++j) s << " + " << e(j);
                         s << ";\n";
@@ -876,12 +886,12 @@ struct CombKernel {
 CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q, int attempt, bool in32, bool out32) {
     Geom g;
     if (!make_geom(tap, hw, q, &g)) return nullptr;
-    if (attempt > 2) return nullptr;
+    if (attempt > 4) return nullptr;
     auto *k = new CombKernel();
     k->geom = g;
     k->in32 = in32;
     k->out32 = out32;
-    const int batch = attempt == 0 ? pick_batch() : attempt == 1 ? 5 : 4;
+    const int batch = attempt == 0 ? pick_batch() : attempt == 1 ? 5 : attempt == 2 ? 4 : attempt == 3 ? 3 : 2;
     k->source = Emitter(k->geom, batch, in32, out32).source();
     return k;
 }

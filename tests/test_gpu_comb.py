@@ -69,6 +69,35 @@ def test_generated_kernel_matches_the_direct_evaluation(monkeypatch, fs, fa):
         assert np.abs(part - ref[:, o0:o0 + olen]).max() <= TOL * np.abs(ref).max(), (fs, fa, direction, "window")
 
 
+@pytest.mark.parametrize("period,div", [(169.2359, 8), (123.08, 8), (101.77, 8), (175.9, 8), (169.5, 12)])
+def test_generated_kernel_wide_teeth(monkeypatch, period, div):
+    """``create_filter(period_half_width=...)`` is the caller's choice (parrm.py:755-756 defaults to period / 50): teeth a
+    quarter or a sixth of the period wide reach 20-25 columns beyond a row (the generator's halo: 12 until round 4, now
+    whatever the LDS holds; the phase-major kernel's guard ends at 6, so these filters ran the stride kernel before)
+    and enter and leave as sliding sums of 20-45 adjacent taps.  Whole recordings (both ends) and a window call against
+    the direct evaluation, two- and one-sided, with omitted samples."""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    rng = np.random.default_rng(int(period * 10 + div))
+    used = 0
+    for direction, omit, hw, n in (("both", 0, 2372, 260_011), ("past", 7, 2372, 200_003), ("future", 0, 650, 150_001)):
+        filt = orc.generate_filter(period, hw, omit, direction, period / div)
+        x = rng.standard_normal((2, n))
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+        state, stride, msg = plan.generated
+        ref = orc.filter_data_direct(x, filt)
+        assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), (period, div, direction, state, msg)
+        if state != 1:
+            assert "scratch" in msg or msg == "", msg  # refused for register spills, or declined: the generic kernels ran
+            continue
+        used += 1
+        o0, olen = n // 3 + 1, n // 5
+        b0, b1 = max(o0 - hw, 0), min(o0 + olen + hw, n)
+        part = plan.apply_window(torch.from_numpy(np.ascontiguousarray(x[:, b0:b1])).cuda(), b0, o0, olen, n).cpu().numpy()
+        assert np.abs(part - ref[:, o0:o0 + olen]).max() <= TOL * np.abs(ref).max(), (period, div, direction, "window")
+    assert used >= 2, "the wide-toothed filters of this period should run the generated kernel"
+
+
 def test_generated_kernel_explicit_half_widths_and_short_recordings(monkeypatch):
     """create_filter's other parameters change the tap geometry the kernel is generated for: shorter and longer
     half-widths (fewer / more rows of reach: other ring sizes), a wide omitted centre, a recording barely longer
