@@ -546,6 +546,20 @@ def main():
             ms64 = launch_ms(lambda: p32.apply(x32, out=y64), 3)
             roof(f"{rows} ch x {n_samples} float32 -> float64 (the reference's dtype rule)", name32(p32, "double"), ms64, 12, rows, n_samples)
             del x32, y64
+            # other sampling geometries on the same 256 ch x 10 M float64 buffers: the reference's own recordings are 1 kHz /
+            # 130 Hz (T = 7.69) and 200 Hz / 150 Hz; a 30 kHz recording has T = 231.  Outside the generated kernel's reach
+            # (short periods: teeth at every residue of a stride; T > 176: a row does not fit 16 lanes x 11 residues): the
+            # phase-major kernel's wrap / guarded forms
+            yg = torch.empty_like(x)
+            for fs_g, fa_g in ((1000.0, 130.0), (30000.0, 130.0)):
+                pg = PARRM(np.zeros((1, n_samples)), fs_g, fa_g, verbose=False)
+                pg._period = np.float64(fs_g / fa_g * (1 + 3e-5))
+                pg.create_filter()
+                plan_g = _hip.FilterPlan(pg.filter)
+                ms_g = launch_ms(lambda: plan_g.apply(x, out=yg), 3)
+                roof(f"{rows} ch x {n_samples} float64, {fs_g:.0f} Hz sampling of {fa_g:.0f} Hz stimulation (T = {fs_g / fa_g:.2f}, {int(plan_g.info.n_taps)} taps)",
+                     kernel_name(plan_g), ms_g, 16, rows, n_samples)
+            del yg
             out["extra"] = {"rooflines": extra}
         if cpu is not None:
             if shared_rows and "period" in cpu:

@@ -18,7 +18,7 @@ import numpy as np
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libparrm_hip.so")
 
 F32, F64 = 0, 1
-KERNEL_AUTO, KERNEL_GATHER, KERNEL_STRIDE, KERNEL_PHASE = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GATHER, KERNEL_STRIDE, KERNEL_PHASE, KERNEL_SEGMENTED = 0, 1, 2, 3, 4
 
 # every symbol include/parrm_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (

@@ -98,6 +98,38 @@ def test_generated_kernel_wide_teeth(monkeypatch, period, div):
     assert used >= 2, "the wide-toothed filters of this period should run the generated kernel"
 
 
+@pytest.mark.parametrize("fs,fa,name", [(200.0, 150.0, "example_data"), (1000.0, 130.0, "ecog_lfp_data"), (30000.0, 130.0, "30 kHz")])
+def test_geometries_outside_the_generators_reach_match_the_direct_evaluation(fs, fa, name):
+    """The sampling geometries of the reference's own shipped recordings (``data/example_data.py:13-30``: 200 Hz / 150 Hz,
+    T = 1.33; 1 kHz / 130 Hz, T = 7.69) and a 30 kHz recording (T = 230.8 > 176): outside the generated kernel's reach --
+    short periods have their teeth at every residue of any stride, 231 residues do not fit 16 lanes x 11 -- so large
+    launches run the generic phase-major kernel (wrap form / guarded form).  Same parity bar against the direct
+    evaluation, default and one-sided filters, >= 2^25 samples so that the launch is one the generator would be asked for."""
+    period = fs / fa * (1 + 2e-4)
+    n_chans, n = 4, 8_500_000
+    assert n_chans * n >= 1 << 25
+    g = torch.Generator(device="cuda").manual_seed(int(fs))
+    x = torch.randn((n_chans, n), dtype=torch.float64, device="cuda", generator=g)
+    for direction, omit in (("both", 0), ("future", 1)):
+        filt, hw = _default_filter(period, n, omit, direction)
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(x)
+        state, stride, msg = plan.generated
+        assert state != 1, "this geometry was outside the generator's reach: update the test's premise"
+        assert plan.info.kernel in (_hip.KERNEL_PHASE, _hip.KERNEL_STRIDE, _hip.KERNEL_SEGMENTED), plan.info.kernel
+        for lo in (0, n // 2 - 20_000, n - 40_000):  # both ends and the middle
+            hi = lo + 40_000
+            b0, b1 = max(lo - hw, 0), min(hi + hw, n)
+            ref = orc.filter_data_direct(x[:, b0:b1].cpu().numpy(), filt)
+            keep = np.ones(b1 - b0, dtype=bool)
+            if b0 > 0:
+                keep[:hw] = False
+            if b1 < n:
+                keep[-hw:] = False
+            got = y[:, b0:b1].cpu().numpy()
+            assert np.abs(got[:, keep] - ref[:, keep]).max() <= TOL * np.abs(ref).max(), (name, direction, lo)
+
+
 def test_generated_kernel_explicit_half_widths_and_short_recordings(monkeypatch):
     """create_filter's other parameters change the tap geometry the kernel is generated for: shorter and longer
     half-widths (fewer / more rows of reach: other ring sizes), a wide omitted centre, a recording barely longer
