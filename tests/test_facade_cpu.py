@@ -378,3 +378,43 @@ def test_create_filter_random_parameters_match_the_oracle():
         np.testing.assert_array_equal(p.filter, want)
         checked += 1
     assert checked > 200 and raised > 0
+
+
+def test_ranking_by_selection_has_the_head_of_the_full_sort():
+    """``_rank_candidates`` ranks a large all-finite grid by selection (the 7 smallest errors) instead of a full
+    ``argsort`` (parrm.py:456-465): what the stage uses of the ranking -- the best <= 5 candidates in order, and the
+    arg-min over [their refined errors, every other error] (:499-522) -- must be what the reference's full sort gives,
+    on grids with exact ties (the full sort runs then), NaN / inf entries (ditto) and plain ones."""
+    from pyparrm_amd import parrm as facade
+
+    def reference_ranking(periods, errors):
+        order = errors.argsort()
+        e = errors[order]
+        return periods[order[np.isfinite(e)]], e
+
+    rng = np.random.default_rng(0)
+    selected = 0
+    for case in range(600):
+        n = int(rng.integers(65, 12000))
+        e = rng.standard_normal(n)
+        if case % 5 == 1:
+            e[rng.integers(0, n, 20)] = e[rng.integers(0, n, 20)]
+        if case % 7 == 2:
+            e[rng.integers(0, n)] = np.nan
+        if case % 11 == 3:
+            e[rng.integers(0, n)] = np.inf
+        if case % 13 == 4:
+            e = np.round(e, 2)
+        per = rng.uniform(100, 200, n)
+        got = facade._rank_candidates(per.copy(), e.copy())
+        want = reference_ranking(per.copy(), e.copy())
+        selected += got[0].shape[0] < want[0].shape[0]
+        k = min(6, got[0].shape[0])
+        assert np.array_equal(got[0][:k], want[0][:k]) and np.array_equal(got[1][:k], want[1][:k], equal_nan=True)
+        refined = want[1][:5] + 0.1 * rng.standard_normal(5)
+        a, b = [v.copy() for v in got], [v.copy() for v in want]
+        a[1][:5] = refined
+        b[1][:5] = refined
+        if not np.isnan(b[1]).any():
+            assert a[0][a[1].argmin()] == b[0][b[1].argmin()]
+    assert selected > 300  # (the selection path is what ran in most cases)
