@@ -16,6 +16,10 @@
 //                             is what lets an f64 stencil approach the HBM roofline (SURVEY.md 7,
 //                             hard part 1).  xz is x zero-padded outside [0, N), so the recurrence
 //                             is exact at the recording edges too; only the divisor changes there.
+#include <chrono>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -355,11 +359,49 @@ bool comb_self_test(const parrm_filter_plan *p, CombKernel *ck, hipStream_t stre
                 if (!(dd <= worst)) worst = dd;  // (NaN counts as a failure)
             }
             // samples are O(1): the direct evaluation rounds at ~1e-15; a float32 output is one rounding of each
-            ok = worst <= (sizeof(TO) == 8 ? 1e-11 : 3e-7);
+            const double bar = sizeof(TO) == 8 ? 1e-11 : 3e-7;
+            ok = worst <= bar;
             if (!ok) {
                 char msg[128];
                 snprintf(msg, sizeof msg, "self-test against the gather kernel failed (max |d| %.3e)", worst);
                 comb_set_error(ck, msg);
+            }
+            // ... and a WINDOW call (the whole-recording case has buf_first = out_first = 0): the buffer
+            // starts inside the recording and the outputs inside the buffer -- what the host-streamed and online
+            // forms launch.  Every tap of every output lies in the buffer or beyond the recording's end.
+            if (ok) {
+                const int64_t bf = comb_reach(ck) + 13, of = bf + p->hw + 5;
+                FilterArgs wa = a, wb = b;
+                for (FilterArgs *w : {&wa, &wb}) {
+                    w->x = d + static_cast<size_t>(bf) * sizeof(TI);
+                    w->buf_first = bf;
+                    w->buf_len = n - bf;
+                    w->out_first = of;
+                    w->out_len = n - of;
+                }
+                rc = launch_comb(ck, &wa, stream);
+                if (rc == PARRM_OK) rc = launch_main<TI, TO>(p, &wb, PARRM_KERNEL_GATHER, stream);
+                if (rc == PARRM_OK) e = hipMemcpyAsync(y1.data(), wa.y, out_bytes, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess && rc == PARRM_OK) e = hipMemcpyAsync(y2.data(), wb.y, out_bytes, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess && rc == PARRM_OK) e = hipStreamSynchronize(stream);
+                if (e == hipSuccess && rc == PARRM_OK) {
+                    double worst_w = 0.0;
+                    for (int64_t ch = 0; ch < c; ++ch)
+                        for (int64_t i = 0; i < n - of; ++i) {
+                            const size_t at = static_cast<size_t>(ch * n + i);
+                            const double dd = std::fabs(static_cast<double>(y1[at]) - static_cast<double>(y2[at]));
+                            if (!(dd <= worst_w)) worst_w = dd;
+                        }
+                    ok = worst_w <= bar;
+                    if (!ok) {
+                        char msg[128];
+                        snprintf(msg, sizeof msg, "self-test (window call) against the gather kernel failed (max |d| %.3e)", worst_w);
+                        comb_set_error(ck, msg);
+                    }
+                } else {
+                    ok = false;
+                    comb_set_error(ck, "self-test (window call) could not run");
+                }
             }
         } else {
             comb_set_error(ck, "self-test could not run");
@@ -421,8 +463,12 @@ const CombKernel *comb_for_launch(const parrm_filter_plan *p, const FilterArgs &
     CombKernel *&ck = p->comb[v];
     int &state = p->comb_state[v];
     if (state == 0) {
+        const auto t_gen0 = std::chrono::steady_clock::now();
         const int64_t q = comb_search_stride(p->tap_mask, p->hw);
         ck = q ? comb_generate(p->tap_mask, p->hw, q, 0, in32, out32) : nullptr;
+        if (getenv("PARRM_COMB_VERBOSE"))
+            fprintf(stderr, "parrm: generated filter kernel: stride search + source in %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gen0).count());
         // Unless forced, only where it has clearly less LDS traffic than the phase-major kernel (whose figure is
         // its number of delta taps): BASELINE geometry 17.8 reads per output against 28.
         if (ck && !force && p->phase.n_groups > 0 && comb_reads_per_output(ck) > 0.8 * (2.0 * p->phase.d_pad)) {
@@ -445,6 +491,12 @@ const CombKernel *comb_for_launch(const parrm_filter_plan *p, const FilterArgs &
             const int device = p->device;
             CombJob *raw = job.get();  // (the plan joins the worker before it goes away: parrm_filter_plan_destroy)
             job->worker = std::thread([p, raw, q, device]() {
+                // One build at a time, at low priority: hipRTC is seconds of CPU on several threads, and three of them at
+                // once starved the calling thread on a 16-core box (a filter_data call of 0.3 ms took 260-310 ms while
+                // two earlier geometries were compiling -- measured, scripts/exp_background_compile.py).
+                static std::mutex build_slot;
+                (void)setpriority(PRIO_PROCESS, static_cast<id_t>(syscall(SYS_gettid)), 15);
+                std::lock_guard<std::mutex> one_at_a_time(build_slot);
                 hipStream_t st = nullptr;
                 if (hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
                     raw->result_state = comb_build<TI, TO>(p, raw->kernel, q, st);

@@ -772,7 +772,18 @@ std::string library_dir() {
 std::string user_cache_dir() {
     if (const char *e = getenv("PARRM_KERNEL_CACHE")) return e;
     if (const char *h = getenv("HOME")) return std::string(h) + "/.cache/pyparrm_amd";
-    return "/tmp/pyparrm_amd_cache";
+    // (no HOME: a directory of this user's own under /tmp -- never one another user can have made first)
+    return "/tmp/pyparrm_amd_cache_" + std::to_string(static_cast<long long>(getuid()));
+}
+
+// A cache directory's code objects are EXECUTED: it is read only when it belongs to this user and nobody else can
+// write to it (the round-3 fallback /tmp/pyparrm_amd_cache was world-visible, created 0755 by whoever got
+// there first; another local user could have planted comb_<hash>.hsaco).  The in-tree <library dir>/kernels/ is part
+// of the installation and trusted like the library itself.
+bool cache_dir_is_safe(const std::string &dir) {
+    struct stat sb;
+    if (stat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
+    return sb.st_uid == getuid() && (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
 bool read_file(const std::string &path, std::vector<char> *out) {
@@ -797,7 +808,7 @@ void make_dirs(const std::string &dir) {
     std::string acc;
     for (size_t i = 0; i <= dir.size(); ++i) {
         if (i == dir.size() || dir[i] == '/') {
-            if (!acc.empty()) (void)mkdir(acc.c_str(), 0755);
+            if (!acc.empty()) (void)mkdir(acc.c_str(), i == dir.size() ? 0700 : 0755);  // (the cache directory itself: this user only)
         }
         if (i < dir.size()) acc.push_back(dir[i]);
     }
@@ -829,9 +840,20 @@ bool compile_source(const std::string &src, std::vector<char> *code, std::string
     return ok;
 }
 
+// The name carries a hash of the source AND of what turns it into code: the target and the hipRTC version (a code
+// object built by another compiler release is not looked up).
 std::string code_name(const std::string &src) {
+    // (asked ONCE: every hipRTC entry point takes the library's global lock, which hiprtcCompileProgram holds for the
+    // whole compile -- a version query from the launching thread sat out a background build's remaining 250-330 ms)
+    static const std::string salt = [] {
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        char buf[64];
+        snprintf(buf, sizeof buf, "|gfx950|hiprtc %d.%d", major, minor);
+        return std::string(buf);
+    }();
     char buf[64];
-    snprintf(buf, sizeof buf, "comb_%016llx.hsaco", static_cast<unsigned long long>(fnv1a(src)));
+    snprintf(buf, sizeof buf, "comb_%016llx.hsaco", static_cast<unsigned long long>(fnv1a(src + salt)));
     return buf;
 }
 
@@ -840,7 +862,7 @@ bool code_for_source(const std::string &src, std::vector<char> *code, std::strin
     const std::string name = code_name(src);
     if (!getenv("PARRM_COMB_NO_CACHE")) {
         if (read_file(library_dir() + "/kernels/" + name, code)) return true;
-        if (read_file(user_cache_dir() + "/" + name, code)) return true;
+        if (cache_dir_is_safe(user_cache_dir()) && read_file(user_cache_dir() + "/" + name, code)) return true;
     }
     std::string log;
     if (!compile_source(src, code, &log)) {
@@ -848,7 +870,7 @@ bool code_for_source(const std::string &src, std::vector<char> *code, std::strin
         return false;
     }
     make_dirs(user_cache_dir());
-    (void)write_file_atomic(user_cache_dir() + "/" + name, *code);
+    if (cache_dir_is_safe(user_cache_dir())) (void)write_file_atomic(user_cache_dir() + "/" + name, *code);
     return true;
 }
 
@@ -933,7 +955,8 @@ bool comb_code_cached(const CombKernel *k) {
     if (getenv("PARRM_COMB_NO_CACHE")) return false;
     const std::string name = code_name(k->source);
     struct stat sb;
-    return stat((library_dir() + "/kernels/" + name).c_str(), &sb) == 0 || stat((user_cache_dir() + "/" + name).c_str(), &sb) == 0;
+    return stat((library_dir() + "/kernels/" + name).c_str(), &sb) == 0 ||
+           (cache_dir_is_safe(user_cache_dir()) && stat((user_cache_dir() + "/" + name).c_str(), &sb) == 0);
 }
 
 const char *comb_error(const CombKernel *k) { return k->error.c_str(); }

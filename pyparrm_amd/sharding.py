@@ -346,20 +346,59 @@ class IpcExchange(Exchange):
 
     @classmethod
     def create(cls, dist):
+        """Probe the mechanism in PHASES THAT EVERY RANK ALWAYS EXECUTES -- allocate, exchange handles, exchange "my
+        mappings opened" flags, copy, exchange "my copies were right" flags -- so that a failure on one rank (a pair
+        without peer access, a handle that does not open) never makes it skip a collective the others are waiting
+        in: every rank learns the verdict in the same call and all of them return None together (the
+        earlier form went from a failed copy straight to the flags while its peers sat in a barrier)."""
         import torch
+        from torch.multiprocessing.reductions import reduce_tensor
 
         group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
         ex = cls(dist, group)
-        ok = True
+        world, rank = ex.world_size, ex.rank
+
+        def agree(ok: bool) -> bool:
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(ok), group=group)
+            return all(flags)
+
+        # phase 1: this rank's buffer and its handle (None: could not be made)
+        handle, ok = None, True
         try:
-            probe = torch.full((1024,), float(ex.rank), dtype=torch.float64, device="cuda")
-            parts = ex.all_gather(probe)
-            ok = all(float(p[0].item()) == float(r) and float(p[-1].item()) == float(r) for r, p in enumerate(parts))
+            ex._mine = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+            ex._mine[:8192].view(torch.float64).fill_(float(rank))
+            torch.cuda.current_stream().synchronize()
+            handle = reduce_tensor(ex._mine)
         except Exception:  # noqa: BLE001 -- any failure means "not usable here"
             ok = False
-        flags = [None] * ex.world_size
-        dist.all_gather_object(flags, bool(ok), group=group)
-        return ex if all(flags) else None
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=group)
+        # phase 2: open the peers' buffers
+        if ok and all(h is not None for h in handles):
+            try:
+                for r, (rebuild, args) in enumerate(handles):
+                    if r != rank:
+                        ex._peers[r] = rebuild(*args)
+            except Exception:  # noqa: BLE001
+                ok = False
+        else:
+            ok = False
+        if not agree(ok):
+            ex._mine, ex._peers = None, {}
+            return None
+        # phase 3: read every peer's pattern through the mapping
+        try:
+            for r, remote in ex._peers.items():
+                got = remote[:8192].view(torch.float64).to("cuda", copy=True)
+                ok = ok and float(got[0].item()) == float(r) and float(got[-1].item()) == float(r)
+            torch.cuda.current_stream().synchronize()
+        except Exception:  # noqa: BLE001
+            ok = False
+        if not agree(ok):
+            ex._mine, ex._peers = None, {}
+            return None
+        return ex
 
     def _ensure(self, nbytes: int, device):
         """Exchange buffers of at least `nbytes` on every rank (all ranks pass pieces of one size, so all grow
