@@ -38,7 +38,9 @@ def search():
 for _ in range(3):
     filt()
 res = {k: [] for k in ("back_to_back", "after_search", "second_after_search", "after_search_idle_2ms", "after_search_idle_20ms",
-                        "after_search_then_absdiff", "after_absdiff_only", "after_idle_20ms")}
+                        "after_search_then_absdiff", "after_absdiff_only", "after_idle_20ms", "after_search_then_touch_8ch",
+                        "after_search_then_touch_32ch", "after_search_then_touch_64ch")}
+touch_total = {8: [], 32: [], 64: []}
 for rep in range(8):
     filt()
     res["back_to_back"].append(filt())
@@ -56,6 +58,15 @@ for rep in range(8):
     search()
     _hip.absdiff_mean(x)
     res["after_search_then_absdiff"].append(filt())
+    for rows in (8, 32, 64):  # a short streaming read of the first rows right in front of the launch
+        search()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _hip.absdiff_mean(x[:rows])
+        res[f"after_search_then_touch_{rows}ch"].append(filt())
+        e1.record()
+        torch.cuda.synchronize()
+        touch_total[rows].append(e0.elapsed_time(e1))
     filt()
     _hip.absdiff_mean(x)
     res["after_absdiff_only"].append(filt())
@@ -66,3 +77,5 @@ for rep in range(8):
 for k, v in res.items():
     v = np.array(v)
     print(f"{k:28s} median {np.median(v):6.3f} ms  min {v.min():6.3f}  max {v.max():6.3f}")
+for rows, v in touch_total.items():
+    print(f"touch {rows} rows + filter launch, events around both: median {np.median(v):6.3f} ms")
