@@ -19,6 +19,10 @@ Fixtures written (``r2_*.npz`` / ``r2_periods.json``):
 * ``float32``     float32 recordings (the reference standardises in float32, parrm.py:272-280).
 * ``fuzz``        60 small recordings over sampling/artefact frequency pairs, channel counts,
                   lengths, detunings and seeds: the reference's period of each.
+* ``args``        round 4: 24 recordings with the ARGUMENTS of ``find_period`` varied (parrm.py:148-155): a
+                  ``search_samples`` window (float ``arange`` as the reference's tests pass it), two or three
+                  ``assumed_periods``, ``outlier_boundary`` 1.5 ... 6, 4-8 channels, 30 000 ... 120 000 samples (stage 3
+                  draws its indices at random there) -- written to ``r4_periods.json``.
 * ``psd``         the reference's ``compute_psd`` (_utils/_power.py:10-68) on three seeded inputs:
                   ``n_points`` below, equal to and above the recording's length (truncation and
                   zero padding), with and without ``max_freq``, float32 and float64 recordings.
@@ -92,6 +96,31 @@ def float32_cases():
     return out
 
 
+def args_cases():
+    """24 deterministic parameter sets with find_period's arguments varied."""
+    rng = np.random.default_rng(20261005)
+    pairs = [(22000.0, 130.0), (1000.0, 130.0), (4000.0, 130.0), (8000.0, 125.0), (2048.0, 140.0), (30000.0, 185.0)]
+    cases = []
+    for i in range(24):
+        fs, fa = pairs[i % len(pairs)]
+        n_samples = int(rng.choice([30000, 45000, 60001, 90000, 120000]))
+        case = dict(tag=f"args{i:02d}", fs=fs, fa=fa, n_chans=int(rng.integers(1, 9)), n_samples=n_samples,
+                    period=fs / fa * (1 + float(rng.uniform(-2e-3, 2e-3))), seed=int(rng.integers(1, 1 << 30)),
+                    random_seed=int(rng.integers(0, 1000)), gain=(2.0, float(rng.choice([4.0, 10.0]))), dtype="float64")
+        kind = i % 4
+        if kind in (0, 3):  # a window of the recording, as a float arange (tests/test_parrm.py:33-36 passes floats)
+            lo = int(rng.integers(0, n_samples // 3))
+            hi = int(rng.integers(n_samples // 2, n_samples))
+            case["search"] = [lo, hi]
+        if kind in (1, 3):  # several assumed periods around the nominal one
+            base = fs / fa
+            case["assumed"] = [base * (1 + d) for d in rng.uniform(-4e-3, 4e-3, int(rng.integers(2, 4)))]
+        if kind in (2, 3):
+            case["outlier"] = float(rng.choice([1.5, 2.0, 4.5, 6.0]))
+        cases.append(case)
+    return cases
+
+
 def _run_case(case):
     PARRM, _ = _import_reference()
     x = synth_recording_exact(case["n_chans"], case["n_samples"], case["period"], case["seed"],
@@ -99,6 +128,10 @@ def _run_case(case):
     t0 = time.time()
     p = PARRM(x, case["fs"], case["fa"], verbose=False)
     kw = {}
+    if "search" in case:
+        kw["search_samples"] = np.arange(float(case["search"][0]), float(case["search"][1]))
+    if "outlier" in case:
+        kw["outlier_boundary"] = case["outlier"]
     if "assumed" in case:
         kw["assumed_periods"] = tuple(case["assumed"])
     try:
@@ -124,6 +157,13 @@ def run_period_sets(workers, only):
         with Pool(workers) as pool:
             done[name] = pool.map(_run_case, cases, chunksize=1)
         json.dump(done, open(path, "w"), indent=1)
+
+
+def run_args(workers):
+    path = os.path.join(HERE, "r4_periods.json")
+    with Pool(workers) as pool:
+        done = {"args": pool.map(_run_case, args_cases(), chunksize=1)}
+    json.dump(done, open(path, "w"), indent=1)
 
 
 def run_grid26(only):
@@ -223,6 +263,8 @@ def main():
     args = ap.parse_args()
     if args.only in (None, "psd"):
         run_psd()
+    if args.only in (None, "args"):
+        run_args(args.workers)
     if args.only in (None, "grid26"):
         run_grid26(args.only)
     if args.only in (None, "cfg1_flow"):

@@ -27,6 +27,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "r2_periods.json")) as fh:
     R2 = json.load(fh)
 
+R4_PATH = os.path.join(HERE, "golden", "r4_periods.json")
+R4 = json.load(open(R4_PATH)) if os.path.exists(R4_PATH) else {"args": []}
+
 PERIOD_RTOL = 1e-9  # only where the comparison is with the ORACLE run on this host's CPU (its libm), not a reference fixture
 
 
@@ -52,6 +55,10 @@ def _run_case(case):
     x = _case_recording(case)
     p = PARRM(x, case["fs"], case["fa"], verbose=False)
     kw = {"assumed_periods": tuple(case["assumed"])} if "assumed" in case else {}
+    if "search" in case:  # (a float arange, as the reference's own tests pass it: tests/test_parrm.py:33-36)
+        kw["search_samples"] = np.arange(float(case["search"][0]), float(case["search"][1]))
+    if "outlier" in case:
+        kw["outlier_boundary"] = case["outlier"]
     p.find_period(random_seed=case["random_seed"], **kw)
     return p
 
@@ -65,6 +72,21 @@ def test_period_matches_reference(case):
     p = _run_case(case)
     assert p.period == ref, (case["tag"], repr(p.period), repr(ref))
     assert _same_default_taps(p.period, ref, case["n_samples"])
+
+
+@pytest.mark.parametrize("case", R4["args"], ids=lambda c: c["tag"])
+def test_period_with_varied_arguments_matches_reference(case):
+    """Round 4: 24 recordings of 1-8 channels x 30 000-120 000 samples with ``find_period``'s ARGUMENTS varied --
+    a ``search_samples`` window, two or three ``assumed_periods``, ``outlier_boundary`` 1.5 ... 6 (parrm.py:148-155,
+    :213-270) -- against the period the unmodified reference found (``tests/golden/r4_periods.json``,
+    ``make_golden_r2.py --only args``): bit-identical."""
+    ref = case["ref_period"]
+    if ref is None:
+        with pytest.raises(ValueError, match="The period cannot be estimated from the data."):
+            _run_case(case)
+        return
+    p = _run_case(case)
+    assert p.period == ref, (case["tag"], repr(p.period), repr(ref))
 
 
 @pytest.mark.parametrize("case", R2["grid26"], ids=lambda c: c["tag"])
