@@ -300,7 +300,7 @@ template <typename TI, typename TO>
 int launch_main(const parrm_filter_plan *p, FilterArgs *args, int kernel, hipStream_t stream);
 
 // The generated kernel (parrm_filter_comb.hip) for this launch, or nullptr: float64 recordings, comb filters
-// with a stride in [80, 176] whose delta taps sit within 12 residues of its multiples.  PARRM_COMB=0 turns it off, PARRM_COMB=force takes it for any size; otherwise a
+// with a stride in [80, 176] whose taps sit within 40 residues of its multiples (as far as the LDS ring holds the halo).  PARRM_COMB=0 turns it off, PARRM_COMB=force takes it for any size; otherwise a
 // launch must be large enough (2^25 samples) to be worth a possible hipRTC compile (seconds, once per filter
 // geometry: code objects are cached on disk).  A failure to generate, compile or load is remembered and the
 // launch falls back to filter_phase_kernel -- same results within the parity bar, never an error.

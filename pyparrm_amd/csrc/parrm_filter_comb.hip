@@ -77,6 +77,7 @@ struct Geom {
     int b_threads = 0, threads = 0;  // stage-B lanes (whole waves >= q); workgroup size
     int ofs = 0, ch16 = 0, d_bytes = 0, nld = 0;  // slot of row m: (m + ofs) mod ms; 16-byte chunks per row; one Delta buffer; loads per lane
     int n_taps = 0;
+    int fsplit = 1;  // 2: rows of HALF the recurrence stride (strides above 176), two running sums per lane (row parity)
     std::vector<Unit> units;
     std::vector<Run> runs;
 };
@@ -86,8 +87,20 @@ inline int floordiv_round(int64_t u, int64_t q) {  // nearest multiple
 }
 
 // Geometry for a tap mask and a stride; false when this kernel cannot take the filter.
+// `q`: the recurrence stride.  Up to 176 a ring row is one stride long.  Above (round 4: a 30 kHz recording of 130 Hz
+// stimulation has T = 231) a row of q residues no longer fits 16 lanes x 11 and the LDS, so rows are HALF a stride
+// (q even): sample n = m q/2 + rho, the delta taps u = a q/2 + b reach back an even number of such rows, and the
+// running sum of a residue advances over TWO rows -- S(n + q) = S(n) + Delta(n) --, i.e. stage B keeps one sum for the
+// even and one for the odd rows of its residue.  Everything else (ring, stage A, loader) is the kernel for stride q/2.
 bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     auto tap_at = [&](int64_t w) -> int { return (w >= -hw && w <= hw) ? tap[w + hw] : 0; };
+    const int64_t stride = q;
+    g->fsplit = 1;
+    if (q > 176) {
+        if (q & 1) return false;
+        g->fsplit = 2;
+        q /= 2;
+    }
     // (16 lanes x C residues cover a row; the ring of 64+ rows and the two Delta buffers fit the LDS up to C = 11)
     if (q < 80 || q > 176) return false;
     g->q = static_cast<int>(q);
@@ -96,8 +109,8 @@ bool make_geom(const std::vector<int8_t> &tap, int64_t hw, int64_t q, Geom *g) {
     g->a_hi = -(1 << 30);
     // delta taps, ascending in u
     std::vector<std::pair<int64_t, int>> delta;
-    for (int64_t u = -hw - q; u <= hw; ++u) {
-        const int d = tap_at(u + q) - tap_at(u);
+    for (int64_t u = -hw - stride; u <= hw; ++u) {
+        const int d = tap_at(u + stride) - tap_at(u);
         if (d == 0) continue;
         delta.push_back({u, d});
         const int a = floordiv_round(u, q);
@@ -204,7 +217,7 @@ class Emitter {
         // 8 no second barrier, 16 no stage B at all, 32 no wait before the ring copy.  Part of the source text, so each has
         // its own code object.
         if (const char *e = getenv("PARRM_COMB_DEBUG")) debug_ = atoi(e);
-        if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0 && !in32 && !out32;
+        if (const char *e = getenv("PARRM_COMB_B16")) wide_b_ = atoi(e) != 0 && !in32 && !out32 && g.fsplit == 1;
         // cache policy of the once-read row requests (bit 0) and the once-written output stores (bit 1): `nt`
         // (part of the source text, like the ablations: every setting is a code object of its own)
         if (const char *e = getenv("PARRM_COMB_NT")) nt_ = atoi(e);
@@ -365,11 +378,12 @@ class Emitter {
             reads.push_back({"dbk", r * g_.dpb});
             std::ostringstream s;
             const int ix = 2 * r;
-            s << "        { const double yv = __builtin_fma(-S, inv_taps, eb" << ix << ");\n";
+            const char *sum = (g_.fsplit == 2 && (r & 1)) ? "SO" : "S";  // (NR is even: the parity of a row is that of r)
+            s << "        { const double yv = __builtin_fma(-" << sum << ", inv_taps, eb" << ix << ");\n";
             if (debug_ & 2) s << "          asm volatile(\"\" :: \"v\"(yv));\n";
             else if (out32_) s << "          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, (float)yv), rsrc_y, yoff, " << r * g_.q * 4 << "u, " << ((nt_ & 2) ? 2 : 0) << ");\n";
             else s << "          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv), rsrc_y, yoff, " << r * g_.q * 8 << "u, " << ((nt_ & 2) ? 2 : 0) << ");\n";
-            s << "          S += eb" << ix + 1 << "; }\n";
+            s << "          " << sum << " += eb" << ix + 1 << "; }\n";
             compute.push_back(s.str());
         }
         emit_pipeline(o, "eb", reads, compute, 6);  // three rows per batch
@@ -475,6 +489,7 @@ class Emitter {
         const Geom &g = g_;
         const int P = g.period;
         o << "// generated by parrm_filter_comb.hip -- q " << g.q << ", C " << g.c << ", " << g.units.size() << " delta units\n";
+        if (g.fsplit == 2) o << "// rows of HALF the recurrence stride (" << 2 * g.q << "): running sums S (even rows) and SO (odd rows)\n";
         o << "typedef unsigned int u32;\ntypedef unsigned int u32x2 __attribute__((ext_vector_type(2)));\n"
           << "typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));\ntypedef double d2 __attribute__((ext_vector_type(2)));\n";
         // element types: XT recording (XB bytes, XSH = log2), YT output (YB bytes); PFT = what one row request returns
@@ -514,6 +529,15 @@ class Emitter {
                 }
         }
         sd << "        S = (sa0 + sa1) + (sa2 + sa3);\n        S1 = (sb0 + sb1) + (sb2 + sb3);\n    }\n";
+        if (g.fsplit == 2) {  // the same for row 1: the running sum of the odd rows
+            sd << "    double SO = 0.0;\n    if (rho < Q) {\n        const double *sdp = reinterpret_cast<const double *>(smem) + (HB + rho);\n"
+               << "        double so0 = 0.0, so1 = 0.0, so2 = 0.0, so3 = 0.0;\n";
+            int n = 0;
+            for (const Run &r : g.runs)
+                for (int b = r.b_lo; b <= r.b_hi; ++b, ++n)
+                    sd << "        so" << (n & 3) << " += sdp[" << (g.ofs + 1 - r.a) * g.pitch - b << "];\n";
+            sd << "        SO = (so0 + so1) + (so2 + so3);\n    }\n";
+        }
         const std::string sdirect = sd.str();
         o << R"SRC(
 struct CombArgs {
@@ -737,7 +761,22 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) KNAME(CombArgs a) {
         o << "    int k = 0;\n    while (true) {\n";
         o << bodies.str();
         o << "    }\n    if (wave_has_b) stage_b_generic(n_iter - 1);\n}\n";
-        return o.str();
+        std::string text = o.str();
+        if (g.fsplit == 2) {  // the generic (edge) form of stage B: the row's parity picks the running sum
+            auto replace_all = [&](const std::string &from, const std::string &to) {
+                size_t at = 0, n = 0;
+                while ((at = text.find(from, at)) != std::string::npos) {
+                    text.replace(at, from.size(), to);
+                    at += to.size();
+                    ++n;
+                }
+                return n;
+            };
+            const size_t a = replace_all("inv_taps, n, xp[0], S);", "inv_taps, n, xp[0], ((m & 1) ? SO : S));");
+            const size_t b = replace_all("                S += dp[0];", "                ((m & 1) ? SO : S) += dp[0];");
+            if (a != 1 || b != 1) return std::string();  // (the template text changed under this patch: no kernel)
+        }
+        return text;
     }
 
    private:
@@ -915,6 +954,10 @@ CombKernel *comb_generate(const std::vector<int8_t> &tap, int64_t hw, int64_t q,
     k->out32 = out32;
     const int batch = attempt == 0 ? pick_batch() : attempt == 1 ? 5 : attempt == 2 ? 4 : attempt == 3 ? 3 : 2;
     k->source = Emitter(k->geom, batch, in32, out32).source();
+    if (k->source.empty()) {
+        delete k;
+        return nullptr;
+    }
     return k;
 }
 
@@ -968,7 +1011,7 @@ double comb_reads_per_output(const CombKernel *k) {
     for (const Unit &u : k->geom.units) reads += k->geom.c + u.width - 1;
     return reads / k->geom.c * (16.0 * k->geom.c) / static_cast<double>(k->geom.q);
 }
-int comb_stride(const CombKernel *k) { return k->geom.q; }
+int comb_stride(const CombKernel *k) { return k->geom.q * k->geom.fsplit; }  // (the recurrence stride)
 
 // The stride this kernel works best at for a tap mask: the one with the fewest LDS reads per output among the
 // strides whose geometry it can take (0: none).  Independent of the generic kernels' choice (the phase-major plan
@@ -976,12 +1019,12 @@ int comb_stride(const CombKernel *k) { return k->geom.q; }
 int64_t comb_search_stride(const std::vector<int8_t> &tap, int64_t hw) {
     int64_t best_q = 0;
     double best = 1e300;
-    for (int64_t q = 80; q <= 176; ++q) {
+    for (int64_t q = 80; q <= 352; ++q) {  // (above 176: even strides, rows of half a stride -- make_geom)
         Geom g;
         if (!make_geom(tap, hw, q, &g)) continue;
         double reads = 0.0;
         for (const Unit &u : g.units) reads += g.c + u.width - 1;
-        const double cost = reads / g.c * (16.0 * g.c) / static_cast<double>(q);  // per real output
+        const double cost = reads / g.c * (16.0 * g.c) / static_cast<double>(g.q);  // per real output (g.q: the row length)
         if (cost < best) {
             best = cost;
             best_q = q;

@@ -34,4 +34,4 @@ for T in periods:
         e0.record(); plan.apply(x, out=y); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print(f"T={T:9.4f} hw={i.half_width:5d} taps={i.n_taps:4d} kernel={i.kernel} q={i.phase_stride:3d} d={i.phase_delta:2d} B={i.phase_guard} "
-          f"NG={i.phase_groups} R={i.phase_rows} M={i.phase_row_slots:3d}: {np.median(ts[1:]):6.2f} ms", flush=True)
+          f"NG={i.phase_groups} R={i.phase_rows} M={i.phase_row_slots:3d}: {np.median(ts[1:]):6.2f} ms  generated {plan.generated}", flush=True)

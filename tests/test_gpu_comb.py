@@ -130,6 +130,32 @@ def test_geometries_outside_the_generators_reach_match_the_direct_evaluation(fs,
             assert np.abs(got[:, keep] - ref[:, keep]).max() <= TOL * np.abs(ref).max(), (name, direction, lo)
 
 
+@pytest.mark.parametrize("fs,fa", [(26000.0, 130.0), (44000.0, 130.0), (45760.0, 130.0), (30000.0, 130.0)], ids=lambda v: str(int(v)))
+def test_generated_kernel_strides_above_176_rows_of_half_a_stride(monkeypatch, fs, fa):
+    """Round 4: artefact periods of 200 ... 352 samples (26-46 kHz sampling of 130 Hz stimulation).  A row of the
+    recurrence stride no longer fits 16 lanes x 11 residues and the LDS, so the generated kernel keeps rows of HALF a
+    stride and two running sums per lane (even and odd rows): whole recordings with both ends, one-sided filters with
+    omitted samples and a window call against the direct evaluation.  (Forced: by default the kernel is only taken
+    where it has clearly fewer LDS reads per output than the phase-major kernel -- not at T = 230.77, whose half
+    stride drifts by 0.4 residues per row.)"""
+    monkeypatch.setenv("PARRM_COMB", "force")
+    period = fs / fa * (1 + 3e-5)
+    rng = np.random.default_rng(int(fs))
+    for direction, omit, n in (("both", 0, 400_019), ("past", 3, 300_007), ("future", 0, 250_001)):
+        filt, hw = _default_filter(period, n, omit, direction)
+        x = rng.standard_normal((3, n))
+        plan = _hip.FilterPlan(filt)
+        y = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+        stride = _in_use(plan, may_decline=True)
+        assert stride > 176 and stride % 2 == 0 and abs(stride - period) < 2.0, (stride, period)
+        ref = orc.filter_data_direct(x, filt)
+        assert np.abs(y - ref).max() <= TOL * np.abs(ref).max(), (fs, fa, direction, omit)
+        o0, olen = n // 3 + 1, n // 4
+        b0, b1 = max(o0 - hw, 0), min(o0 + olen + hw, n)
+        part = plan.apply_window(torch.from_numpy(np.ascontiguousarray(x[:, b0:b1])).cuda(), b0, o0, olen, n).cpu().numpy()
+        assert np.abs(part - ref[:, o0:o0 + olen]).max() <= TOL * np.abs(ref).max(), (fs, fa, direction, "window")
+
+
 def test_generated_kernel_explicit_half_widths_and_short_recordings(monkeypatch):
     """create_filter's other parameters change the tap geometry the kernel is generated for: shorter and longer
     half-widths (fewer / more rows of reach: other ring sizes), a wide omitted centre, a recording barely longer
