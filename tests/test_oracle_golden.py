@@ -179,6 +179,31 @@ def test_oracle_period_matches_reference_r2(tag):
     assert float(got) == case["ref_period"]
 
 
+@pytest.mark.parametrize("tag", ["args20", "args15", "args22"])
+def test_oracle_period_matches_reference_r4_arguments(tag):
+    """Round-4 fixtures (``make_golden_r2.py --only args``): ``find_period`` with its ARGUMENTS varied -- a float
+    ``search_samples`` window (args20), two assumed periods + ``outlier_boundary`` 2.0 + a window (args15),
+    ``outlier_boundary`` 6.0 (args22) -- the oracle's whole search against the unmodified reference's period, bit for
+    bit (parrm.py:213-270 sorts and validates the window, :272-280 clips at the boundary, :376-405 builds the grid)."""
+    import json
+
+    from pyparrm_amd.synth import synth_recording_exact
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r4_periods.json")) as fh:
+        case = next(c for c in json.load(fh)["args"] if c["tag"] == tag)
+    x = synth_recording_exact(case["n_chans"], case["n_samples"], case["period"], case["seed"],
+                              gain_range=tuple(case["gain"]))
+    kw = {}
+    if "search" in case:
+        kw["search_samples"] = np.arange(float(case["search"][0]), float(case["search"][1]))
+    if "assumed" in case:
+        kw["assumed_periods"] = tuple(case["assumed"])
+    if "outlier" in case:
+        kw["outlier_boundary"] = case["outlier"]
+    got = orc.find_period(x, case["fs"], case["fa"], random_seed=case["random_seed"], **kw)
+    assert float(got) == case["ref_period"]
+
+
 def test_r2_fixture_inventory():
     fixtures = _r2()
     assert len(fixtures["fuzz"]) == 60 and len(fixtures["short"]) == 5
