@@ -51,6 +51,23 @@ pre = {
     "80 optimiser batches on 8 channels": lambda: [_hip.fit_errors(y_small, idx3, grid3[:9], 20, 1.0, ws2) for _ in range(80)],
     "search": search,
 }
+side = torch.cuda.Stream()
+z = torch.empty_like(x[:64])
+
+
+def batches_with_traffic(y_mat, w):
+    """the 80 batches with a streaming copy of 64 rows (10 GB of traffic, ~2 ms each) looping on a side stream beside them"""
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(5):
+            z.copy_(x[:64])
+    for _ in range(80):
+        _hip.fit_errors(y_mat, idx3, grid3[:9], 20, 1.0, w)
+    torch.cuda.current_stream().wait_stream(side)
+
+
+pre["80 batches on 8 channels + streaming copies beside them"] = lambda: batches_with_traffic(y_small, ws2)
+pre["80 batches (256 ch) + streaming copies beside them"] = lambda: batches_with_traffic(y3, ws)
 res = {k: [] for k in pre}
 for _ in range(3):
     filt()
